@@ -1,0 +1,435 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors by RUNNING THE REFERENCE (build container only).
+
+    python tests/golden/make_golden.py
+
+Every expected output in `tests/golden/*.npz` is produced by the reference's own
+functions (`bark.forest.*`, `bark.fitting.quick_inverse.*`,
+`bark.fitting.bark_prior_sampler._sample_single_forest`, and
+`bofire_mixed/benchmarks/tree_function.py`) imported from `/root/reference/src`
+through `_ref_shim.py` (identity-njit == the reference's NUMBA_DISABLE_JIT mode),
+plus `numpy.linalg.inv/slogdet` exactly where the reference calls them
+(`examples/mcmc/mcmc_record_mll.py:57-74`, `bark/tree_kernels/tree_gps.py:80-113`,
+`bark/fitting/bark_sampler.py:153-162`).  `forest_predict` itself cannot be imported
+(gpytorch/beartype absent), so G6 evaluates its 12 numpy lines on top of the
+reference's `batched_forest_gram_matrix`; this is recorded in the fixture's `meta`.
+
+Forests are stored as raw bytes of the packed 26-byte NODE_RECORD_DTYPE
+(`forest.py:8-19`) so the fixtures do not depend on numpy dtype pickling.
+"""
+
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_shim  # noqa: E402
+
+ref = _ref_shim.reference_modules()
+F = ref.forest
+QI = ref.quick_inverse
+DT = F.NODE_RECORD_DTYPE
+assert DT.itemsize == 26
+
+CAT, INT, CONT = 0, 1, 2
+
+
+def raw(nodes):
+    nodes = np.ascontiguousarray(nodes)
+    return nodes.view(np.uint8).reshape(*nodes.shape, DT.itemsize).copy()
+
+
+def save(name, meta, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path}  ({os.path.getsize(path)} B)")
+
+
+def prior_forests(B, m, bounds, feat_types, seed, alpha=0.95, beta=2.0):
+    """B forests from the reference prior sampler (bark_prior_sampler.py:15-65)."""
+    out = []
+    for b in range(B):
+        np.random.seed(seed + b)  # sample_splitting_rule uses the global RNG
+        rng = np.random.default_rng(seed + b)
+        out.append(ref.prior._sample_single_forest(m, bounds, feat_types, alpha, beta, rng))
+    return np.array(out)
+
+
+def mll_example(forest, noise, X, y, feat_types):
+    """examples/mcmc/mcmc_record_mll.py:57-74 (no scale, with n*log(2pi))."""
+    n = X.shape[0]
+    forest = forest.reshape(-1, *forest.shape[-2:])
+    noise = noise.reshape(-1)
+    K = F.batched_forest_gram_matrix(forest, X, X, feat_types)
+    Ks = K + (1e-6 + noise[:, None, None]) * np.eye(n)
+    K_inv = np.linalg.inv(Ks)
+    _, K_logdet = np.linalg.slogdet(Ks)
+    yy = y[None, ...]
+    data_fit = (yy.transpose((0, 2, 1)) @ K_inv @ yy).squeeze()
+    return 0.5 * (-data_fit - K_logdet - n * np.log(2 * np.pi))
+
+
+def mll_sampler(forest, noise, scale, X, y, feat_types):
+    """bark_sampler.py:153-162 per forest (with scale, quick_inverse.mll)."""
+    out = []
+    for b in range(forest.shape[0]):
+        K = scale[b] * F.forest_gram_matrix(forest[b], X, X, feat_types)
+        Ks = K + (1e-6 + noise[b]) * np.eye(K.shape[0])
+        K_inv = np.linalg.inv(Ks)
+        _, K_logdet = np.linalg.slogdet(Ks)
+        out.append(QI.mll(K_inv, K_logdet, y))
+    return np.array(out)
+
+
+def predict_lines(forest, noise, scale, X, y, cand, feat_types):
+    """tree_gps.py:87-112 evaluated on the reference's batched Gram."""
+    forest = forest.reshape(-1, *forest.shape[-2:])
+    noise = noise.reshape(-1)
+    scale = scale.reshape(-1)
+    S, C = scale.shape[0], cand.shape[0]
+    K_XX = scale[:, None, None] * F.batched_forest_gram_matrix(forest, X, X, feat_types)
+    K_XX_s = K_XX + (1e-6 + noise[:, None, None]) * np.eye(X.shape[0])
+    K_inv = np.linalg.inv(K_XX_s)
+    K_xX = scale[:, None, None] * F.batched_forest_gram_matrix(forest, cand, X, feat_types)
+    mu = K_xX @ K_inv @ y
+    var = scale[:, None, None] - K_xX @ K_inv @ K_xX.transpose((0, 2, 1))
+    mu = mu.reshape(S, C)
+    return mu, np.diagonal(var, axis1=1, axis2=2).copy(), var
+
+
+# --------------------------------------------------------------------------------------
+def g1_kat_tree():
+    # tests/tree_models/test_forest.py:6-20 restated with the 8th field (`active`)
+    nodes = np.array(
+        [
+            (0, 0, 0.5, 1, 2, 0, 0, 1),
+            (0, 0, 0.25, 3, 4, 0, 1, 1),
+            (1, 0, 1.0, 0, 0, 0, 1, 1),
+            (1, 0, 1.0, 0, 0, 1, 2, 1),
+            (1, 0, 1.0, 0, 0, 1, 2, 1),
+        ],
+        dtype=DT,
+    ).reshape(1, -1)
+    x = np.linspace(0, 1, 20).reshape(-1, 1)
+    ft = np.array([CONT])
+    leaves = F.pass_through_forest(nodes, x, ft)
+    K = F.forest_gram_matrix(nodes, x, x, ft)
+    lv = F.get_leaf_vectors(nodes[0], x, ft)
+    save("g1_kat_tree", {"src": "tests/tree_models/test_forest.py:6-20 (8-field restatement)"},
+         nodes=raw(nodes), x=x, feat_types=ft, leaves=leaves, K=K, leaf_vectors=lv)
+
+
+def g2_two_tree_kat():
+    # tests/bark_fitting/test_quick_inverse.py:55-101 restated with 8 fields
+    forest = np.zeros((2, 5), dtype=DT)
+    forest[0, 0] = (1, 0, 0, 0, 0, 0, 0, 1)
+    forest[1, 0] = (0, 0, 0.5, 1, 2, 0, 0, 1)
+    forest[1, 1] = (0, 0, 0.25, 3, 4, 0, 1, 1)
+    forest[1, 2] = (1, 0, 0, 0, 0, 0, 1, 1)
+    forest[1, 3] = (1, 0, 0, 0, 0, 1, 2, 1)
+    forest[1, 4] = (1, 0, 0, 0, 0, 1, 2, 1)
+    new_nodes = forest[0].copy()
+    new_nodes[0] = (0, 0, 0.75, 1, 2, 0, 0, 1)
+    new_nodes[1] = (1, 0, 0, 0, 0, 0, 1, 1)
+    new_nodes[2] = (1, 0, 0, 0, 0, 0, 1, 1)
+
+    x = np.linspace(0, 1, 20).reshape(-1, 1)
+    ft = np.array([CONT])
+    scale, noise = 0.5, 0.1
+    K = F.forest_gram_matrix(forest, x, x, ft)
+    K_XX_s = scale * K + noise * np.eye(20)
+    K_inv = np.linalg.inv(K_XX_s)
+    _, K_logdet = np.linalg.slogdet(K_XX_s)
+
+    s_sqrtm = np.sqrt(scale / forest.shape[0])
+    cur_lv = s_sqrtm * F.get_leaf_vectors(forest[0], x, ft)
+    new_lv = s_sqrtm * F.get_leaf_vectors(new_nodes, x, ft)
+    inv1 = QI.low_rank_inv_update(K_inv, cur_lv, subtract=True)
+    det1 = QI.low_rank_det_update(K_inv, cur_lv, K_logdet, subtract=True)
+    inv2 = QI.low_rank_inv_update(inv1, new_lv)
+    det2 = QI.low_rank_det_update(inv1, new_lv, det1)
+
+    forest2 = forest.copy()
+    forest2[0] = new_nodes
+    K2 = F.forest_gram_matrix(forest2, x, x, ft)
+    K2_s = scale * K2 + noise * np.eye(20)
+    K2_inv = np.linalg.inv(K2_s)
+    _, K2_logdet = np.linalg.slogdet(K2_s)
+    assert np.isclose(K2_logdet, det2) and np.isclose(K2_inv, inv2).all()
+
+    save("g2_two_tree_kat",
+         {"src": "tests/bark_fitting/test_quick_inverse.py:55-101 (8-field restatement)",
+          "scale": scale, "noise": noise},
+         forest=raw(forest), new_nodes=raw(new_nodes), x=x, feat_types=ft,
+         K=K, K_inv=K_inv, K_logdet=np.float64(K_logdet),
+         cur_leaf_vectors=cur_lv, new_leaf_vectors=new_lv,
+         inv_after_subtract=inv1, det_after_subtract=np.float64(det1),
+         inv_after_add=inv2, det_after_add=np.float64(det2),
+         K_swapped=K2, K_swapped_inv=K2_inv, K_swapped_logdet=np.float64(K2_logdet))
+
+
+def mixed_problem(N, seed, d_cont=6, n_cat=2, n_int=0, cats=5):
+    rng = np.random.default_rng(seed)
+    cols, bounds, ft = [], [], []
+    for _ in range(d_cont):
+        cols.append(rng.uniform(size=N))
+        bounds.append((0.0, 1.0))
+        ft.append(CONT)
+    for _ in range(n_int):
+        cols.append(rng.integers(0, 11, size=N).astype(np.float64))
+        bounds.append((0.0, 10.0))
+        ft.append(INT)
+    for _ in range(n_cat):
+        cols.append(rng.integers(0, cats, size=N).astype(np.float64))
+        bounds.append((0.0, float((1 << cats) - 1)))
+        ft.append(CAT)
+    X = np.stack(cols, axis=1)
+    y = rng.standard_normal((N, 1))
+    y = (y - y.mean()) / y.std()
+    return X, y, np.array(bounds), np.array(ft)
+
+
+def g3_prior_mixed():
+    for N in (64, 257):
+        X, y, bounds, ft = mixed_problem(N, seed=N)
+        B, m = 3, 50
+        forest = prior_forests(B, m, bounds, ft, seed=1000 + N)
+        # make one forest contain some null trees and one forest deeper trees (alpha high)
+        for attempt in range(50):
+            np.random.seed(77 + N + attempt)
+            try:
+                deep = ref.prior._sample_single_forest(
+                    m, bounds, ft, 0.95, 0.9, np.random.default_rng(77 + N + attempt))
+                break
+            except OverflowError:  # tree_proposals.py:58 — container (L=100) exhausted, redraw
+                continue
+        forest[2] = deep
+        noise = np.array([0.1, 0.05, 0.2])
+        scale = np.array([1.0, 0.7, 1.3])
+        leaves = np.stack([F.pass_through_forest(forest[b], X, ft) for b in range(B)])
+        K = F.batched_forest_gram_matrix(forest, X, X, ft)
+        K_nn = F.batched_forest_gram_matrix_no_null(forest, X, X, ft)
+        save(f"g3_prior_mixed_n{N}",
+             {"src": "bark_prior_sampler.py:15-65 + forest.py:58-111 + mcmc_record_mll.py:57-74 "
+                     "+ bark_sampler.py:153-162", "N": N, "m": m, "B": B},
+             forest=raw(forest), X=X, y=y, bounds=bounds, feat_types=ft,
+             noise=noise, scale=scale, leaves=leaves, K=K, K_no_null=K_nn,
+             mll_example=mll_example(forest, noise, X, y, ft),
+             mll_sampler=mll_sampler(forest, noise, scale, X, y, ft))
+
+
+def g4_all_null():
+    m = 7
+    forest = ref.empty_forest(m)[None]
+    X, y, _, ft = mixed_problem(33, seed=4)
+    leaves = F.pass_through_forest(forest[0], X, ft)
+    K = F.batched_forest_gram_matrix(forest, X, X, ft)
+    K_nn = F.batched_forest_gram_matrix_no_null(forest, X, X, ft)
+    noise = np.array([0.3])
+    save("g4_all_null", {"src": "forest.py:114-117 empty forest; K==1 everywhere"},
+         forest=raw(forest), X=X, y=y, feat_types=ft, leaves=leaves, K=K, K_no_null=K_nn,
+         noise=noise, mll_example=np.atleast_1d(mll_example(forest, noise, X, y, ft)))
+
+
+def g5_boundaries():
+    # one tree per case family; thresholds chosen so float32 rounding matters
+    thr32 = np.float32(0.1)  # 0.100000001490116...
+    t64 = float(thr32)
+    forest = np.zeros((3, 9), dtype=DT)
+    # tree 0: continuous split on f0 at float32(0.1), then right child splits f1 at 0.5
+    forest[0, 0] = (0, 0, thr32, 5, 7, 0xFFFFFFFF, 0, 1)
+    forest[0, 5] = (1, 0, 0, 0, 0, 0, 1, 1)
+    forest[0, 7] = (0, 1, 0.5, 2, 8, 0, 1, 1)
+    forest[0, 2] = (1, 0, 0, 0, 0, 7, 2, 1)
+    forest[0, 8] = (1, 0, 0, 0, 0, 7, 2, 1)
+    # tree 1: integer feature f2 split at 3 (x<=3 left), left child splits at 0
+    forest[1, 0] = (0, 2, 3.0, 1, 2, 0xFFFFFFFF, 0, 1)
+    forest[1, 1] = (0, 2, 0.0, 3, 4, 0, 1, 1)
+    forest[1, 2] = (1, 0, 0, 0, 0, 0, 1, 1)
+    forest[1, 3] = (1, 0, 0, 0, 0, 1, 2, 1)
+    forest[1, 4] = (1, 0, 0, 0, 0, 1, 2, 1)
+    # tree 2: categorical f3, mask 0b0110 ; right child: mask 0b1000 on same feature
+    forest[2, 0] = (0, 3, 6.0, 1, 2, 0xFFFFFFFF, 0, 1)
+    forest[2, 1] = (1, 0, 0, 0, 0, 0, 1, 1)
+    forest[2, 2] = (0, 3, 8.0, 3, 4, 0, 1, 1)
+    forest[2, 3] = (1, 0, 0, 0, 0, 2, 2, 1)
+    forest[2, 4] = (1, 0, 0, 0, 0, 2, 2, 1)
+    ft = np.array([CONT, CONT, INT, CAT])
+    f0 = [t64, np.nextafter(t64, 1.0), np.nextafter(t64, 0.0), 0.1, 0.0, -0.0, 1.0,
+          np.nan, np.inf, -np.inf, 0.09999999, 0.10000001]
+    rows = []
+    for i, a in enumerate(f0):
+        rows.append([a, [0.5, np.nextafter(0.5, 1), np.nan, 0.25][i % 4],
+                     float([0, 3, 4, -1, 10, 2][i % 6]), float(i % 5)])
+    # categorical values 0..4 plus a large (out of mask) category 30 and fractional 2.9 (truncates to 2)
+    rows.append([0.5, 0.5, 3.0, 30.0])
+    rows.append([0.5, 0.5, 3.0, 2.9])
+    rows.append([0.5, 0.5, 3.5, 1.0])
+    X = np.array(rows, dtype=np.float64)
+    leaves = F.pass_through_forest(forest, X, ft)
+    K = F.forest_gram_matrix(forest, X, X, ft)
+    save("g5_boundaries", {"src": "forest.py:28-47 edge semantics: x==thr(f32), nextafter, NaN, inf, "
+                                  "-0.0, int split, categorical bitmask, truncation toward zero"},
+         forest=raw(forest), X=X, feat_types=ft, leaves=leaves, K=K)
+
+
+def g6_predict():
+    N, C = 64, 33
+    X, y, bounds, ft = mixed_problem(N, seed=66)
+    cand, _, _, _ = mixed_problem(C, seed=67)
+    B, m = 4, 50
+    forest = prior_forests(B, m, bounds, ft, seed=660)
+    noise = np.array([0.1, 0.07, 0.15, 0.12])
+    scale = np.array([1.0, 0.8, 1.2, 0.95])
+    # shape (chains=2, samples=2, ...) to exercise the flatten at tree_gps.py:88-90
+    mu, var_diag, var_full = predict_lines(forest, noise, scale, X, y, cand, ft)
+    K_xX = F.batched_forest_gram_matrix(forest, cand, X, ft)
+    mu_y = np.mean(mu, axis=0)
+    var_y = np.mean(var_diag + mu**2, axis=0) - mu_y**2  # tree_gps.py:129-131
+    save("g6_predict",
+         {"src": "tree_gps.py:87-112 evaluated on reference batched_forest_gram_matrix (forest_predict "
+                 "itself needs gpytorch at import); mixture: tree_gps.py:129-131",
+          "N": N, "C": C, "B": B},
+         forest=raw(forest.reshape(2, 2, m, -1)), noise=noise.reshape(2, 2), scale=scale.reshape(2, 2),
+         X=X, y=y, cand=cand, feat_types=ft, K_xX=K_xX, mu=mu, var=var_diag, var_full=var_full,
+         mix_mu=mu_y, mix_var=var_y)
+
+
+def g7_tree_function():
+    """Config c1: TreeFunction(dim=5, m=50, function_seed=1) at 64 seeded points.
+
+    `tree_function.py` imports bofire/matplotlib at module top; they are absent, so empty
+    placeholder modules satisfy the imports and the two *functions* that define the
+    benchmark (`sample_tree_structure_from_prior` :36-57, `sample_tree_function_from_structure`
+    :19-33) are called with a minimal domain object (5 continuous inputs), exactly what
+    `TreeFunction.__init__` (:65-88) passes them for the default arguments.
+    """
+    class _Cont:  # placeholder for bofire ContinuousInput
+        pass
+
+    class _Cat:
+        pass
+
+    class _Disc:
+        pass
+
+    def _mod(name, **attrs):
+        mod = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(mod, k, v)
+        sys.modules[name] = mod
+        return mod
+
+    obj = type("_P", (), {})
+    _mod("bofire")
+    _mod("bofire.benchmarks")
+    _mod("bofire.benchmarks.api", Benchmark=object)
+    _mod("bofire.data_models")
+    _mod("bofire.data_models.domain")
+    _mod("bofire.data_models.domain.api", Domain=obj, Inputs=obj, Outputs=obj, Features=obj)
+    _mod("bofire.data_models.enum", CategoricalEncodingEnum=obj)
+    _mod("bofire.data_models.features")
+    _mod("bofire.data_models.features.api", CategoricalInput=_Cat, ContinuousInput=_Cont,
+         ContinuousOutput=obj, DiscreteInput=_Disc, AnyFeature=obj)
+    _mod("bofire.data_models.objectives")
+    _mod("bofire.data_models.objectives.api", MinimizeObjective=obj)
+    if "matplotlib" not in sys.modules:
+        try:
+            import matplotlib.pyplot  # noqa: F401
+        except Exception:
+            _mod("matplotlib")
+            _mod("matplotlib.pyplot")
+
+    # bofire_mixed/__init__ imports the whole plugin; load the two files by path instead
+    import importlib.util
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    _mod("bofire_mixed")
+    load("bofire_mixed.domain", "/root/reference/src/bofire_mixed/domain.py")
+    tf = load("ref_tree_function", "/root/reference/src/bofire_mixed/benchmarks/tree_function.py")
+    tf.create_empty_forest = ref.empty_forest  # numpy-2-safe ctor, same record
+
+    class _Inputs(list):
+        def get(self):
+            return list(self)
+
+    dim, m, seed = 5, 50, 1
+    domain = types.SimpleNamespace(inputs=_Inputs(_Cont() for _ in range(dim)))
+    rng = np.random.default_rng(seed)  # tree_function.py:86
+    forest = tf.sample_tree_structure_from_prior(m, domain, rng)
+    # sample_tree_function_from_structure draws leaf_values from the same rng (:23)
+    state_before = rng.bit_generator.state
+    f = tf.sample_tree_function_from_structure(forest, domain, rng)
+    leaf_values = np.random.default_rng(0)
+    leaf_values.bit_generator.state = state_before
+    leaf_values = leaf_values.standard_normal(forest.shape)
+    X = np.random.default_rng(64).uniform(size=(64, dim))
+    yv = f(X)
+    ft = np.full(dim, CONT)
+    leaves = F.pass_through_forest(forest, X, ft)
+    assert np.allclose(leaf_values[np.arange(m), leaves].sum(axis=1), yv)
+    save("g7_tree_function",
+         {"src": "bofire_mixed/benchmarks/tree_function.py:19-57,65-88 defaults dim=5 m=50 seed=1; "
+                 "X=default_rng(64).uniform((64,5))"},
+         forest=raw(forest), leaf_values=leaf_values, X=X, y=yv, feat_types=ft, leaves=leaves)
+
+
+def g8_batched_mll():
+    N = 96
+    X, y, bounds, ft = mixed_problem(N, seed=88, d_cont=5, n_cat=1, n_int=2)
+    B, m = 4, 50
+    forest = prior_forests(B, m, bounds, ft, seed=880)
+    noise = np.array([0.05, 0.1, 0.15, 0.08])
+    scale = np.array([1.0, 1.1, 0.9, 1.05])
+    K = F.batched_forest_gram_matrix(forest, X, X, ft)
+    save("g8_batched_mll",
+         {"src": "mcmc_record_mll.py:57-74 and bark_sampler.py:153-162; d = 5 cont + 2 int + 1 cat",
+          "N": N, "B": B},
+         forest=raw(forest), X=X, y=y, bounds=bounds, feat_types=ft, noise=noise, scale=scale, K=K,
+         mll_example=mll_example(forest, noise, X, y, ft),
+         mll_sampler=mll_sampler(forest, noise, scale, X, y, ft))
+
+
+def g9_woodbury():
+    # tests/bark_fitting/test_quick_inverse.py:13-52 inputs, outputs from the reference functions
+    out = {}
+    for i, (N, B, seed) in enumerate([(5, 2, 42), (4, 2, 43), (6, 3, 44)]):
+        rng = np.random.default_rng(seed)
+        A = rng.standard_normal((N, N))
+        U = rng.standard_normal((N, B)) * 0.1
+        _, logdet = np.linalg.slogdet(A)
+        A_inv = np.linalg.inv(A)
+        out[f"A{i}"], out[f"U{i}"], out[f"Ainv{i}"], out[f"logdet{i}"] = A, U, A_inv, np.float64(logdet)
+        out[f"inv_add{i}"] = QI.low_rank_inv_update(A_inv, U, subtract=False)
+        out[f"inv_sub{i}"] = QI.low_rank_inv_update(A_inv, U, subtract=True)
+        out[f"det_add{i}"] = np.float64(QI.low_rank_det_update(A_inv, U, logdet))
+        out[f"det_sub{i}"] = np.float64(QI.low_rank_det_update(A_inv, U, logdet, subtract=True))
+    save("g9_woodbury", {"src": "tests/bark_fitting/test_quick_inverse.py:13-52; quick_inverse.py:13-38"}, **out)
+
+
+if __name__ == "__main__":
+    g1_kat_tree()
+    g2_two_tree_kat()
+    g3_prior_mixed()
+    g4_all_null()
+    g5_boundaries()
+    g6_predict()
+    g7_tree_function()
+    g8_batched_mll()
+    g9_woodbury()
+    # the reference tree must stay clean
+    import subprocess
+
+    dirty = subprocess.run(["find", "/root/reference", "-name", "__pycache__"], capture_output=True, text=True).stdout
+    assert dirty.strip() == "", dirty
