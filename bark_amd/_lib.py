@@ -1,0 +1,145 @@
+"""ctypes binding of libbarkhip.so (include/bark_hip.h) + device plumbing.
+
+torch is used here only as the device-memory container (allocation, H2D/D2H copies, the
+current HIP stream); every computation goes through the C ABI.  There is no CPU fallback:
+if the library is missing or no GPU is visible the product path raises.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbarkhip.so")
+
+BARK_OK = 0
+BARK_ERR_ARG, BARK_ERR_TREE, BARK_ERR_CATEGORICAL, BARK_ERR_HIP, BARK_ERR_WORKSPACE = 1, 2, 3, 4, 5
+MLL_INCLUDE_SCALE, MLL_INCLUDE_2PI = 1, 2
+
+i64, vp, ci = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int
+
+
+class PackInfo(ctypes.Structure):
+    _fields_ = [
+        ("B", i64), ("m", i64), ("L", i64), ("stride", i64),
+        ("max_leaves", i64), ("max_depth", i64), ("packed_bytes", i64),
+    ]
+
+
+class MllTiming(ctypes.Structure):
+    _fields_ = [
+        ("gram_ms", ctypes.c_float), ("chol_ms", ctypes.c_float), ("panel_ms", ctypes.c_float),
+        ("n_panel_launches", i64), ("panel_flops", ctypes.c_double),
+    ]
+
+
+# every exported symbol of include/bark_hip.h: name -> (restype, argtypes)
+SIGNATURES = {
+    "bark_version": (ci, []),
+    "bark_last_error": (ctypes.c_char_p, []),
+    "bark_forest_pack_info": (ci, [vp, i64, i64, i64, vp, i64, ctypes.POINTER(PackInfo)]),
+    "bark_forest_pack": (ci, [vp, vp, i64, ctypes.POINTER(PackInfo), vp]),
+    "bark_leaf_indices_hip": (ci, [vp, ctypes.POINTER(PackInfo), vp, i64, i64, vp, vp]),
+    "bark_leaf_npad": (i64, [i64]),
+    "bark_leaf_bytes_hip": (ci, [vp, ctypes.POINTER(PackInfo), vp, i64, i64, vp, vp]),
+    "bark_gram_from_leaves_hip": (ci, [vp, i64, vp, i64, i64, i64, i64, vp, vp, vp, vp, i64, i64, vp]),
+    "bark_mll_workspace_bytes": (ctypes.c_size_t, [i64, i64, i64, i64]),
+    "bark_mll_batched_hip": (ci, [vp, ctypes.POINTER(PackInfo), vp, i64, i64, vp, vp, vp, ci, vp, i64, vp, vp, vp, vp,
+                                  vp, ctypes.c_size_t, i64, ctypes.POINTER(MllTiming), vp]),
+    "bark_quadform_hip": (ci, [vp, vp, i64, vp, vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Load libbarkhip.so (raises if it has not been built: no silent fallback)."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f"{LIB_PATH} is missing: build it with `make -C bark_amd/csrc` "
+                        "(or __graft_entry__.build()); bark_amd has no CPU fallback")
+                handle = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(handle, name)
+                    fn.restype, fn.argtypes = res, args
+                _lib = handle
+    return _lib
+
+
+def check(rc: int):
+    """Map a C status to the exception type the reference would raise."""
+    if rc == BARK_OK:
+        return
+    msg = lib().bark_last_error().decode(errors="replace")
+    if rc in (BARK_ERR_ARG, BARK_ERR_TREE, BARK_ERR_CATEGORICAL):
+        raise ValueError(f"bark_hip: {msg}")
+    if rc == BARK_ERR_WORKSPACE:
+        raise MemoryError(f"bark_hip: {msg}")
+    raise RuntimeError(f"bark_hip: {msg} (status {rc})")
+
+
+def torch_device():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("bark_amd needs an AMD Instinct GPU (HIP device) — no CPU fallback exists")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_ptr():
+    import torch
+
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device (or host numpy) pointer as c_void_p; None -> NULL."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    if isinstance(t, np.ndarray):
+        return ctypes.c_void_p(t.ctypes.data)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def to_device(a, dtype=None):
+    """numpy / torch (any device) -> contiguous torch tensor on the GPU."""
+    import torch
+
+    dev = torch_device()
+    if isinstance(a, torch.Tensor):
+        t = a.to(device=dev, dtype=dtype) if dtype is not None else a.to(dev)
+        return t.contiguous()
+    arr = np.ascontiguousarray(a)
+    t = torch.from_numpy(arr)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(dev, non_blocking=False)
+
+
+_workspace = None
+
+
+def workspace(nbytes: int):
+    """A cached, 256-byte aligned device scratch buffer that only grows."""
+    import torch
+
+    global _workspace
+    if _workspace is None or _workspace.numel() < nbytes or _workspace.device != torch_device():
+        _workspace = None  # release before growing
+        _workspace = torch.empty(int(nbytes), dtype=torch.uint8, device=torch_device())
+        assert _workspace.data_ptr() % 256 == 0
+    return _workspace
+
+
+def release_workspace():
+    global _workspace
+    _workspace = None

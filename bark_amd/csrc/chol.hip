@@ -1,0 +1,611 @@
+// Batched GP marginal log-likelihood + posterior on gfx950.
+//
+// Reference semantics (paths under /root/reference):
+//   examples/mcmc/mcmc_record_mll.py:57-74      K_s = K + (1e-6+noise) I ; 0.5(-y'K_s^-1 y - log|K_s| - n log 2pi)
+//   src/bark/fitting/bark_sampler.py:153-162    K_s = scale K + (1e-6+noise) I ; quick_inverse.mll (:37-38)
+//   src/bark/tree_kernels/tree_gps.py:80-113    mu = K_xX K_s^-1 y ; var = scale - diag(K_xX K_s^-1 K_Xx)
+// The reference does LU `inv` + LU `slogdet` per forest; here every forest sample of a chunk is
+// factorised as K_s = U'U (U upper triangular, row-major) by a LEFT-LOOKING blocked Cholesky
+// whose three kernels advance all Bc matrices of the chunk in lock step (block size 128):
+//
+//   diag_kernel  (1 workgroup / matrix)   D = P_jj - U[j-1,j]'U[j-1,j]; U_jj = chol(D); W_j = U_jj^-1;
+//                                         z_j = W_j' y_j; logdet += 2 sum log diag; quad += |z_j|^2
+//   panel_kernel (1 workgroup / 128x128 tile) T[j,i] = A[j,i] - sum_{k<j} U[k,j]' U[k,i]   (fp64 MFMA, K = 128 j)
+//                                         plus the partial diagonal tile P_{j+1,j+1} (same sum, k < j)
+//   solve_kernel (1 workgroup / tile)     U[j,i] = W_j' T[j,i]  (MFMA, K = 128);  y_i -= U[j,i]' z_j
+//
+// The candidate block of the posterior (K_Xx, N x C) is appended as extra block columns, so the
+// same sweep yields V = U^-T K_Xx; then mu = V'z and var = scale - colsumsq(V).
+//
+// Why left-looking: every U tile is written once and each trailing tile is accumulated in
+// registers over the whole K range, instead of a read-modify-write of the trailing matrix per
+// step.  Why lock step over the batch: the serial 128x128 potrf/inverse of one matrix occupies
+// one CU; with Bc >= 256 matrices resident in the 288 GB of HBM all CUs do it at once, and the
+// MFMA panel kernel always has Bc x (tiles per block row) workgroups.
+//
+// MFMA: v_mfma_f64_16x16x4_f64.  Operand maps (lane l): A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
+// D reg v: row = (l>>4) + 4v, col = l&15.  Both GEMM operands are "k-major" panels of U (rows = k,
+// 128 contiguous columns), so a panel row is one 1 KiB coalesced wave load and the LDS image
+// As[k][128(+16 pad)] is read conflict-free by ds_read_b64 (row stride 1152 B == 128 mod 256).
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+
+namespace bark {
+
+int launch_gram(const uint32_t *leaf1, int npad1, const uint32_t *leaf2, int npad2, int64_t B, int64_t m, int N, int M,
+                int Nout, int Mout, const double *shift, const double *scale, const double *noise, double *out, int64_t ld,
+                int64_t batch_stride, bool pad_identity, bool upper_only, bool seven_bit, hipStream_t stream);
+
+namespace {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+constexpr int NB = TILE;         // 128
+constexpr int BK = 16;           // k rows per LDS stage
+constexpr int LDS_LD = NB + 16;  // padded row (doubles)
+constexpr int STAGE = 2 * BK * LDS_LD;  // A rows then B rows, doubles
+constexpr int GEMM_LDS_DOUBLES = 2 * STAGE;
+constexpr int THREADS = 256;
+constexpr int SS = NB + 1;  // row stride of the 128x128 factor image in LDS
+
+struct Lane {
+    int wr, wc, lr, lk;
+};
+
+__device__ __forceinline__ Lane lane_of(int tid) {
+    Lane q;
+    const int wave = tid >> 6, l = tid & 63;
+    q.wr = wave >> 1;
+    q.wc = wave & 1;
+    q.lr = l & 15;
+    q.lk = l >> 4;
+    return q;
+}
+
+// element (row, col) inside the 128x128 tile held by acc[mt][nt][v] of this lane
+__device__ __forceinline__ int acc_row(const Lane &q, int mt, int v) { return q.wr * 64 + mt * 16 + q.lk + 4 * v; }
+__device__ __forceinline__ int acc_col(const Lane &q, int nt) { return q.wc * 64 + nt * 16 + q.lr; }
+
+__device__ __forceinline__ void zero_acc(f64x4 (&acc)[4][4]) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f64x4){0.0, 0.0, 0.0, 0.0};
+}
+
+struct StageRegs {
+    f64x2 a0, a1, a2, a3, b0, b1, b2, b3;
+};
+
+// global -> registers: stage kt of both panels; thread (lrow, lcol) moves 4 x 16 B per operand
+__device__ __forceinline__ void stage_load(StageRegs &r, const double *__restrict__ A, long lda,
+                                           const double *__restrict__ B, long ldb, int kt, int lrow, int lcol) {
+    const double *a = A + ((long)kt * BK + lrow) * lda + lcol;
+    const double *b = B + ((long)kt * BK + lrow) * ldb + lcol;
+    r.a0 = *reinterpret_cast<const f64x2 *>(a);
+    r.a1 = *reinterpret_cast<const f64x2 *>(a + 4 * lda);
+    r.a2 = *reinterpret_cast<const f64x2 *>(a + 8 * lda);
+    r.a3 = *reinterpret_cast<const f64x2 *>(a + 12 * lda);
+    r.b0 = *reinterpret_cast<const f64x2 *>(b);
+    r.b1 = *reinterpret_cast<const f64x2 *>(b + 4 * ldb);
+    r.b2 = *reinterpret_cast<const f64x2 *>(b + 8 * ldb);
+    r.b3 = *reinterpret_cast<const f64x2 *>(b + 12 * ldb);
+}
+
+// registers -> LDS stage image As[k][LDS_LD] | Bs[k][LDS_LD]
+__device__ __forceinline__ void stage_store(const StageRegs &r, double *st, int lrow, int lcol) {
+    double *as = st + lrow * LDS_LD + lcol;
+    double *bs = as + BK * LDS_LD;
+    *reinterpret_cast<f64x2 *>(as) = r.a0;
+    *reinterpret_cast<f64x2 *>(as + 4 * LDS_LD) = r.a1;
+    *reinterpret_cast<f64x2 *>(as + 8 * LDS_LD) = r.a2;
+    *reinterpret_cast<f64x2 *>(as + 12 * LDS_LD) = r.a3;
+    *reinterpret_cast<f64x2 *>(bs) = r.b0;
+    *reinterpret_cast<f64x2 *>(bs + 4 * LDS_LD) = r.b1;
+    *reinterpret_cast<f64x2 *>(bs + 8 * LDS_LD) = r.b2;
+    *reinterpret_cast<f64x2 *>(bs + 12 * LDS_LD) = r.b3;
+}
+
+// acc[r][c] += sum_{k<K} A[k][r] * B[k][c]   for a 128x128 tile; A, B k-major panels (row stride lda/ldb,
+// 128 contiguous doubles per row, 16-byte aligned).  K % 16 == 0.  All 256 threads; ends with a barrier.
+__device__ __forceinline__ void gemm_kmajor(f64x4 (&acc)[4][4], const double *__restrict__ A, long lda,
+                                            const double *__restrict__ B, long ldb, int K, double *lds, int tid,
+                                            const Lane &q) {
+    const int nk = K / BK;
+    if (nk == 0) return;
+    // thread -> (row k, column pair) of a stage: 4 passes of 256 threads x 16 B cover 16 rows x 1 KiB
+    const int lrow = tid >> 6, lcol = (tid & 63) * 2;
+    StageRegs regs;
+    stage_load(regs, A, lda, B, ldb, 0, lrow, lcol);
+    stage_store(regs, lds, lrow, lcol);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) stage_load(regs, A, lda, B, ldb, kt + 1, lrow, lcol);
+        const double *As = lds + (kt & 1) * STAGE;
+        const double *Bs = As + BK * LDS_LD;
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            const double *ar = As + (kk * 4 + q.lk) * LDS_LD + q.wr * 64 + q.lr;
+            const double *br = Bs + (kk * 4 + q.lk) * LDS_LD + q.wc * 64 + q.lr;
+            const double a0 = ar[0], a1 = ar[16], a2 = ar[32], a3 = ar[48];
+            const double b0 = br[0], b1 = br[16], b2 = br[32], b3 = br[48];
+#define BARK_MFMA(mt, nt, av, bv) acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[mt][nt], 0, 0, 0)
+            BARK_MFMA(0, 0, a0, b0); BARK_MFMA(0, 1, a0, b1); BARK_MFMA(0, 2, a0, b2); BARK_MFMA(0, 3, a0, b3);
+            BARK_MFMA(1, 0, a1, b0); BARK_MFMA(1, 1, a1, b1); BARK_MFMA(1, 2, a1, b2); BARK_MFMA(1, 3, a1, b3);
+            BARK_MFMA(2, 0, a2, b0); BARK_MFMA(2, 1, a2, b1); BARK_MFMA(2, 2, a2, b2); BARK_MFMA(2, 3, a2, b3);
+            BARK_MFMA(3, 0, a3, b0); BARK_MFMA(3, 1, a3, b1); BARK_MFMA(3, 2, a3, b2); BARK_MFMA(3, 3, a3, b3);
+#undef BARK_MFMA
+        }
+        if (more) stage_store(regs, lds + ((kt + 1) & 1) * STAGE, lrow, lcol);
+        __syncthreads();
+    }
+}
+
+struct Mats {
+    double *A;            // (Bc, Npad, ld)
+    long ld, bstride;
+    double *W;            // (Bc, 128, 128)  inverse of the current diagonal factor
+    double *yz;           // (Bc, Npad)      y on entry, z = U^-T y on exit
+    double *accum;        // (Bc, 2)         quad, logdet
+    int32_t *info;        // (Bc,)
+    int nrb;              // row blocks  (Npad / 128)
+    int ncb;              // column blocks incl. candidate blocks
+};
+
+// ---------------------------------------------------------------------------------------------
+// diag_kernel: factor + invert the j-th diagonal block of every matrix of the chunk.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS) void diag_kernel(Mats p, int j) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const Lane q = lane_of(tid);
+    double *Ab = p.A + (size_t)b * p.bstride;
+    double *tile = Ab + (size_t)j * NB * p.ld + (size_t)j * NB;
+
+    f64x4 acc[4][4];
+    zero_acc(acc);
+    if (j > 0) {
+        const double *prev = Ab + (size_t)(j - 1) * NB * p.ld + (size_t)j * NB;  // U[j-1, j]
+        gemm_kmajor(acc, prev, p.ld, prev, p.ld, NB, lds, tid, q);
+    }
+    double *S = lds;                 // [128][129]
+    double *urow = lds + NB * SS;    // [128]
+    double *tmp = urow + NB;         // [128]
+    double *psum = tmp + NB;         // [2][128]
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int r = acc_row(q, mt, v), c = acc_col(q, nt);
+                S[r * SS + c] = tile[(size_t)r * p.ld + c] - acc[mt][nt][v];
+            }
+    __syncthreads();
+
+    // --- unblocked right-looking Cholesky of the upper triangle (D = U'U) in LDS ---------------
+    const int c = tid & (NB - 1), h = tid >> 7;
+    double logsum = 0.0;
+    int bad = 0;
+    for (int k = 0; k < NB; ++k) {
+        double d = S[k * SS + k];
+        if (!(d > 0.0)) {  // not positive definite (or NaN): flag the first pivot, keep going finite
+            if (!bad) bad = k + 1;
+            d = 1.0;
+        }
+        const double piv = sqrt(d);
+        if (h == 0 && c > k) urow[c] = S[k * SS + c] / piv;
+        if (tid == 0) logsum += log(piv);
+        __syncthreads();
+        if (c > k) {
+            const double ukc = urow[c];
+            for (int r = k + 1 + h; r <= c; r += 2) S[r * SS + c] = fma(-urow[r], ukc, S[r * SS + c]);
+            if (h == 0) S[k * SS + c] = ukc;
+        } else if (c == k && h == 0) {
+            S[k * SS + k] = piv;
+        }
+        __syncthreads();
+    }
+
+    // --- in-place inverse of the upper-triangular factor (column sweep, LAPACK dtrti2 order) ---
+    for (int jj = 0; jj < NB; ++jj) {
+        if (tid < jj) tmp[tid] = S[tid * SS + jj];
+        const double dinv = 1.0 / S[jj * SS + jj];
+        __syncthreads();
+        if (c < jj) {
+            const int mid = (c + jj + 1) >> 1;
+            const int lo = h ? mid : c, hi = h ? jj : mid;
+            double s = 0.0;
+            for (int l = lo; l < hi; ++l) s = fma(S[c * SS + l], tmp[l], s);
+            psum[h * NB + c] = s;
+        }
+        __syncthreads();
+        if (tid < jj) S[tid * SS + jj] = -dinv * (psum[tid] + psum[NB + tid]);
+        if (tid == jj) S[jj * SS + jj] = dinv;
+        __syncthreads();
+    }
+
+    // --- W_j out (explicit zeros below the diagonal: solve_kernel multiplies the full tile) -----
+    double *Wb = p.W + (size_t)b * NB * NB;
+    for (int e = tid; e < NB * NB; e += THREADS) {
+        const int r = e >> 7, cc = e & (NB - 1);
+        Wb[e] = (r <= cc) ? S[r * SS + cc] : 0.0;
+    }
+
+    // --- z_j = W_j' y_j ; quad += |z_j|^2 ; logdet += 2 sum log u_kk ----------------------------
+    double *yb = p.yz + (size_t)b * p.nrb * NB + (size_t)j * NB;
+    if (tid < NB) urow[tid] = yb[tid];
+    __syncthreads();
+    double zz = 0.0;
+    if (tid < NB) {
+        double z = 0.0;
+        for (int r = 0; r <= tid; ++r) z = fma(S[r * SS + tid], urow[r], z);
+        yb[tid] = z;
+        zz = z * z;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) zz += __shfl_xor(zz, off);
+    if ((tid & 63) == 0) psum[tid >> 6] = zz;
+    __syncthreads();
+    if (tid == 0) {
+        p.accum[(size_t)b * 2 + 0] += psum[0] + psum[1];
+        p.accum[(size_t)b * 2 + 1] += 2.0 * logsum;
+        if (bad && p.info[b] == 0) p.info[b] = j * NB + bad;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// panel_kernel: T[j,i] = A[j,i] - sum_{k<j} U[k,j]' U[k,i]  for i > j (all column blocks), and the
+// partial diagonal tile (j+1, j+1).  blockIdx.x = tile, blockIdx.y = matrix.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS, 2) void panel_kernel(Mats p, int j, int n_right) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const Lane q = lane_of(tid);
+    double *Ab = p.A + (size_t)b * p.bstride;
+    int rb, cb;
+    if ((int)blockIdx.x < n_right) {
+        rb = j;
+        cb = j + 1 + blockIdx.x;
+    } else {
+        rb = cb = j + 1;
+    }
+    f64x4 acc[4][4];
+    zero_acc(acc);
+    gemm_kmajor(acc, Ab + (size_t)rb * NB, p.ld, Ab + (size_t)cb * NB, p.ld, j * NB, lds, tid, q);
+    double *tile = Ab + (size_t)rb * NB * p.ld + (size_t)cb * NB;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            double *row = tile + (size_t)acc_row(q, mt, v) * p.ld;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int cc = acc_col(q, nt);
+                row[cc] = row[cc] - acc[mt][nt][v];
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// solve_kernel: U[j,i] = W_j' T[j,i] for every tile right of the diagonal; y_i -= U[j,i]' z_j.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS, 2) void solve_kernel(Mats p, int j) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const Lane q = lane_of(tid);
+    const int cb = j + 1 + blockIdx.x;
+    double *Ab = p.A + (size_t)b * p.bstride;
+    double *tile = Ab + (size_t)j * NB * p.ld + (size_t)cb * NB;
+    const double *Wb = p.W + (size_t)b * NB * NB;
+
+    f64x4 acc[4][4];
+    zero_acc(acc);
+    // D[r][c] = sum_k W[k][r] T[k][c]
+    gemm_kmajor(acc, Wb, NB, tile, p.ld, NB, lds, tid, q);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            double *row = tile + (size_t)acc_row(q, mt, v) * p.ld;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) row[acc_col(q, nt)] = acc[mt][nt][v];
+        }
+    if (cb >= p.nrb) return;  // candidate columns: no right-hand-side update
+
+    // y_i[c] -= sum_r U[j,i][r][c] * z_j[r]
+    double *zs = lds;            // [128]
+    double *part = lds + NB;     // [2][128]
+    const double *zb = p.yz + (size_t)b * p.nrb * NB + (size_t)j * NB;
+    if (tid < NB) zs[tid] = zb[tid];
+    __syncthreads();
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const double z = zs[acc_row(q, mt, v)];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) s[nt] = fma(acc[mt][nt][v], z, s[nt]);
+        }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        s[nt] += __shfl_xor(s[nt], 16);
+        s[nt] += __shfl_xor(s[nt], 32);
+        if (q.lk == 0) part[q.wr * NB + acc_col(q, nt)] = s[nt];
+    }
+    __syncthreads();
+    if (tid < NB) {
+        double *yi = p.yz + (size_t)b * p.nrb * NB + (size_t)cb * NB;
+        yi[tid] = yi[tid] - (part[tid] + part[NB + tid]);
+    }
+}
+
+// yz[b][:] = y (zero padded); accum = 0; info = 0
+__global__ void init_rhs_kernel(const double *__restrict__ y, int N, int npad, double *yz, double *accum,
+                                int32_t *info) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < npad) yz[(size_t)b * npad + i] = i < N ? y[i] : 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        accum[(size_t)b * 2] = 0.0;
+        accum[(size_t)b * 2 + 1] = 0.0;
+        info[b] = 0;
+    }
+}
+
+// quick_inverse.py:38 / mcmc_record_mll.py:73
+__global__ void finish_mll_kernel(const double *accum, int Bc, int N, int include_2pi, double *mll) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= Bc) return;
+    double v = -accum[(size_t)b * 2] - accum[(size_t)b * 2 + 1];
+    if (include_2pi) v = v - (double)N * log(2.0 * M_PI);
+    mll[b] = 0.5 * v;
+}
+
+// mu[c] = sum_r V[r][c] z[r] ; var[c] = scale - sum_r V[r][c]^2      (V = U^-T K_Xx, candidate columns)
+__global__ void predict_reduce_kernel(Mats p, int N, int C, const double *scale, double *mu, double *var) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double *V = p.A + (size_t)b * p.bstride + (size_t)p.nrb * NB + c;
+    const double *z = p.yz + (size_t)b * p.nrb * NB;
+    double m = 0.0, s2 = 0.0;
+    for (int r = 0; r < N; ++r) {
+        const double v = V[(size_t)r * p.ld];
+        m = fma(v, z[r], m);
+        s2 = fma(v, v, s2);
+    }
+    mu[(size_t)b * C + c] = m;
+    var[(size_t)b * C + c] = scale[b] - s2;
+}
+
+// y' K_inv y  (quick_inverse.py:38), one workgroup, grid-stride rows
+__global__ __launch_bounds__(THREADS) void quadform_kernel(const double *__restrict__ Kinv,
+                                                           const double *__restrict__ y, int N, double *out) {
+    __shared__ double red[THREADS / 64];
+    double total = 0.0;
+    for (int r = blockIdx.x; r < N; r += gridDim.x) {
+        double s = 0.0;
+        for (int c = threadIdx.x; c < N; c += THREADS) s = fma(Kinv[(size_t)r * N + c], y[c], s);
+        total = fma(s, y[r], total);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+struct Layout {
+    int64_t npad, cpad, ncols, ld, W;
+    size_t off_A, off_W, off_yz, off_acc, off_leafx, off_leafc, total;
+};
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+Layout make_layout(int64_t N, int64_t C, int64_t m, int64_t Bc) {
+    Layout L;
+    L.npad = round_up(N, NB);
+    L.cpad = C > 0 ? round_up(C, NB) : 0;
+    L.ncols = L.npad + L.cpad;
+    L.ld = L.ncols + 16;  // +128 B: consecutive rows of a tile do not alias the same HBM channel set
+    L.W = (m + 3) / 4;
+    size_t o = 0;
+    L.off_A = o;
+    o = align256(o + (size_t)Bc * L.npad * L.ld * sizeof(double));
+    L.off_W = o;
+    o = align256(o + (size_t)Bc * NB * NB * sizeof(double));
+    L.off_yz = o;
+    o = align256(o + (size_t)Bc * L.npad * sizeof(double));
+    L.off_acc = o;
+    o = align256(o + (size_t)Bc * 2 * sizeof(double));
+    L.off_leafx = o;
+    o = align256(o + (size_t)Bc * L.W * L.npad * sizeof(uint32_t));
+    L.off_leafc = o;
+    o = align256(o + (size_t)Bc * L.W * L.cpad * sizeof(uint32_t));
+    L.total = o;
+    return L;
+}
+
+constexpr size_t DIAG_LDS = (size_t)(NB * SS + 4 * NB) * sizeof(double);
+constexpr size_t GEMM_LDS = (size_t)GEMM_LDS_DOUBLES * sizeof(double);
+static_assert(DIAG_LDS >= GEMM_LDS, "diag kernel reuses its LDS for the K=128 GEMM stage");
+
+int set_lds_limits() {
+    static bool done = false;
+    if (done) return BARK_OK;
+    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(diag_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)DIAG_LDS));
+    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(panel_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
+    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(solve_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
+    done = true;
+    return BARK_OK;
+}
+
+}  // namespace
+}  // namespace bark
+
+using namespace bark;
+
+extern "C" {
+
+size_t bark_mll_workspace_bytes(int64_t N, int64_t C, int64_t m, int64_t Bc) {
+    if (N < 1 || C < 0 || m < 1 || Bc < 1) return 0;
+    return make_layout(N, C, m, Bc).total;
+}
+
+int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
+                         const double *y, const double *noise, const double *scale, int flags, const double *cand,
+                         int64_t C, double *mll_out, double *mu_out, double *var_out, int32_t *info_out,
+                         void *workspace, size_t workspace_bytes, int64_t Bc, bark_mll_timing *timing, void *stream_) {
+    error_buffer()[0] = 0;
+    if (!packed || !info || !X || !y || !noise || !mll_out || !info_out || !workspace)
+        return fail(BARK_ERR_ARG, "bark_mll_batched_hip: null argument");
+    const int64_t B = info->B, m = info->m;
+    if (N < 1 || d < 1 || B < 1 || C < 0 || Bc < 1 || N > (1 << 24) || C > (1 << 24))
+        return fail(BARK_ERR_ARG, "bark_mll_batched_hip: bad shape N=%lld d=%lld B=%lld C=%lld Bc=%lld", (long long)N,
+                    (long long)d, (long long)B, (long long)C, (long long)Bc);
+    if (C > 0 && (!cand || !mu_out || !var_out || !scale || !(flags & BARK_MLL_INCLUDE_SCALE)))
+        return fail(BARK_ERR_ARG, "posterior predictive needs cand, mu_out, var_out, scale and BARK_MLL_INCLUDE_SCALE");
+    if ((flags & BARK_MLL_INCLUDE_SCALE) && !scale) return fail(BARK_ERR_ARG, "BARK_MLL_INCLUDE_SCALE without scale");
+    if (info->max_leaves > 256) return fail(BARK_ERR_ARG, "more than 256 leaves per tree is not supported");
+    if (Bc > B) Bc = B;
+    if (Bc > 65535) Bc = 65535;
+    const Layout L = make_layout(N, C, m, Bc);
+    if (workspace_bytes < L.total)
+        return fail(BARK_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", workspace_bytes, L.total);
+    if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(BARK_ERR_ARG, "workspace must be 256-byte aligned");
+    int rc = set_lds_limits();
+    if (rc) return rc;
+
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    char *ws = static_cast<char *>(workspace);
+    Mats p;
+    p.A = reinterpret_cast<double *>(ws + L.off_A);
+    p.ld = L.ld;
+    p.bstride = L.npad * L.ld;
+    p.W = reinterpret_cast<double *>(ws + L.off_W);
+    p.yz = reinterpret_cast<double *>(ws + L.off_yz);
+    p.accum = reinterpret_cast<double *>(ws + L.off_acc);
+    p.nrb = (int)(L.npad / NB);
+    p.ncb = (int)(L.ncols / NB);
+    uint32_t *leafx = reinterpret_cast<uint32_t *>(ws + L.off_leafx);
+    uint32_t *leafc = reinterpret_cast<uint32_t *>(ws + L.off_leafc);
+    const bool seven = info->max_leaves <= 128;
+    const bool use_scale = (flags & BARK_MLL_INCLUDE_SCALE) != 0;
+
+    std::vector<hipEvent_t> ev;  // timing mode only: [gram0, gram1/chol0, chol1] per chunk + 2 per panel launch
+    auto mark = [&]() -> int {
+        if (!timing) return BARK_OK;
+        hipEvent_t e;
+        BARK_HIP_CHECK(hipEventCreate(&e));
+        BARK_HIP_CHECK(hipEventRecord(e, stream));
+        ev.push_back(e);
+        return BARK_OK;
+    };
+    std::vector<size_t> gram_marks, chol_marks, panel_marks;
+    double panel_flops = 0.0;
+    int64_t panel_launches = 0;
+
+    for (int64_t c0 = 0; c0 < B; c0 += Bc) {
+        const int64_t bc = (B - c0 < Bc) ? (B - c0) : Bc;
+        bark_pack_info sub = *info;
+        sub.B = bc;
+        const char *packed_c = static_cast<const char *>(packed) + (size_t)c0 * m * info->stride * 16;
+        p.info = info_out + c0;
+
+        if (timing) gram_marks.push_back(ev.size());
+        if ((rc = mark())) return rc;
+        if ((rc = bark_leaf_bytes_hip(packed_c, &sub, X, N, d, leafx, stream))) return rc;
+        rc = launch_gram(leafx, (int)L.npad, leafx, (int)L.npad, bc, m, (int)N, (int)N, (int)L.npad, (int)L.npad,
+                         nullptr, use_scale ? scale + c0 : nullptr, noise + c0, p.A, L.ld, p.bstride, true, true, seven, stream);
+        if (rc) return rc;
+        if (C > 0) {
+            if ((rc = bark_leaf_bytes_hip(packed_c, &sub, cand, C, d, leafc, stream))) return rc;
+            rc = launch_gram(leafx, (int)L.npad, leafc, (int)L.cpad, bc, m, (int)N, (int)C, (int)L.npad, (int)L.cpad,
+                             nullptr, scale + c0, nullptr, p.A + L.npad, L.ld, p.bstride, false, false, seven, stream);
+            if (rc) return rc;
+        }
+        {
+            dim3 g((unsigned)((L.npad + 255) / 256), (unsigned)bc);
+            hipLaunchKernelGGL(init_rhs_kernel, g, dim3(256), 0, stream, y, (int)N, (int)L.npad, p.yz, p.accum, p.info);
+            BARK_LAUNCH_CHECK();
+        }
+        if ((rc = mark())) return rc;  // end of gram == start of chol
+
+        for (int j = 0; j < p.nrb; ++j) {
+            hipLaunchKernelGGL(diag_kernel, dim3((unsigned)bc), dim3(THREADS), DIAG_LDS, stream, p, j);
+            BARK_LAUNCH_CHECK();
+            const int n_right = p.ncb - j - 1;
+            const int n_diag = (j + 1 < p.nrb) ? 1 : 0;
+            if (j >= 1 && n_right + n_diag > 0) {
+                if (timing) panel_marks.push_back(ev.size());
+                if ((rc = mark())) return rc;
+                hipLaunchKernelGGL(panel_kernel, dim3((unsigned)(n_right + n_diag), (unsigned)bc), dim3(THREADS),
+                                   GEMM_LDS, stream, p, j, n_right);
+                BARK_LAUNCH_CHECK();
+                if ((rc = mark())) return rc;
+                panel_flops += 2.0 * NB * NB * (double)(j * NB) * (double)(n_right + n_diag) * (double)bc;
+                ++panel_launches;
+            }
+            if (n_right > 0) {
+                hipLaunchKernelGGL(solve_kernel, dim3((unsigned)n_right, (unsigned)bc), dim3(THREADS), GEMM_LDS, stream,
+                                   p, j);
+                BARK_LAUNCH_CHECK();
+            }
+        }
+        hipLaunchKernelGGL(finish_mll_kernel, dim3((unsigned)((bc + 255) / 256)), dim3(256), 0, stream, p.accum, (int)bc,
+                           (int)N, (flags & BARK_MLL_INCLUDE_2PI) ? 1 : 0, mll_out + c0);
+        BARK_LAUNCH_CHECK();
+        if (C > 0) {
+            dim3 g((unsigned)((C + 255) / 256), (unsigned)bc);
+            hipLaunchKernelGGL(predict_reduce_kernel, g, dim3(256), 0, stream, p, (int)N, (int)C, scale + c0,
+                               mu_out + (size_t)c0 * C, var_out + (size_t)c0 * C);
+            BARK_LAUNCH_CHECK();
+        }
+        if (timing) chol_marks.push_back(ev.size());
+        if ((rc = mark())) return rc;
+    }
+
+    if (timing) {
+        BARK_HIP_CHECK(hipStreamSynchronize(stream));
+        auto span = [&](size_t a, size_t b_, float *acc) -> int {
+            float ms = 0.f;
+            BARK_HIP_CHECK(hipEventElapsedTime(&ms, ev[a], ev[b_]));
+            *acc += ms;
+            return BARK_OK;
+        };
+        timing->gram_ms = timing->chol_ms = timing->panel_ms = 0.f;
+        for (size_t k = 0; k < gram_marks.size(); ++k) {
+            // chunk k: events [g0, g1 (== chol start), (panel pairs...), chol end]
+            if ((rc = span(gram_marks[k], gram_marks[k] + 1, &timing->gram_ms))) return rc;
+            if ((rc = span(gram_marks[k] + 1, chol_marks[k], &timing->chol_ms))) return rc;
+        }
+        for (size_t a : panel_marks)
+            if ((rc = span(a, a + 1, &timing->panel_ms))) return rc;
+        timing->n_panel_launches = panel_launches;
+        timing->panel_flops = panel_flops;
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    }
+    return BARK_OK;
+}
+
+int bark_quadform_hip(const double *K_inv, const double *y, int64_t N, double *out, void *stream_) {
+    error_buffer()[0] = 0;
+    if (!K_inv || !y || !out || N < 1 || N > (1 << 30)) return fail(BARK_ERR_ARG, "bark_quadform_hip: bad argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    BARK_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(double), stream));
+    const int grid = (int)(N < 1024 ? N : 1024);
+    hipLaunchKernelGGL(quadform_kernel, dim3(grid), dim3(THREADS), 0, stream, K_inv, y, (int)N, out);
+    BARK_LAUNCH_CHECK();
+    return BARK_OK;
+}
+
+}  // extern "C"

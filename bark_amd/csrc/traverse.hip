@@ -1,0 +1,139 @@
+// Leaf traversal on gfx950 — src/bark/forest.py:28-67 (_pass_one_through_tree,
+// pass_through_tree, pass_through_forest).
+//
+// One thread owns one data point and walks every tree of one forest; a workgroup is 256
+// points of one forest sample.  The point's feature row sits in LDS (odd row stride, so the
+// data-dependent `x[feature]` reads spread over banks); the handful of live nodes per tree
+// come from the packed wire format (pack.cpp) through L1/L2 — every lane starts at the same
+// root, so those loads are mostly broadcasts.  The walk is bounded by the packer's
+// `max_depth`, so every wave terminates whatever the node bytes contain.
+//
+// Integer output, must be bit-identical to the reference:
+//   categorical:  (1 << int(x[f])) & int(threshold)  != 0  -> left       (forest.py:37-39)
+//   otherwise  :  x[f] <= float64(float32 threshold)       -> left       (forest.py:41)
+//   NaN compares false -> right.
+#include "common.h"
+
+namespace bark {
+namespace {
+
+constexpr int WALK_THREADS = 256;
+
+template <bool X_IN_LDS>
+__device__ __forceinline__ uint4 walk_tree(const uint4 *__restrict__ tree, int max_depth, const double *xrow) {
+    uint4 n = tree[0];
+    for (int step = 0; step < max_depth && !(n.x & LEAF_FLAG); ++step) {
+        const uint32_t f = n.x & FEAT_MASK;
+        const double xv = xrow[f];
+        bool left;
+        if (n.x & CAT_FLAG) {
+            const double xt = trunc(xv);  // int(): toward zero; NaN/negative never match (host rejects them)
+            left = (xt >= 0.0 && xt < 32.0) ? ((n.y >> (uint32_t)xt) & 1u) : false;
+        } else {
+            left = xv <= (double)__uint_as_float(n.y);
+        }
+        n = tree[left ? n.z : n.w];
+    }
+    return n;
+}
+
+// MODE 0: out[b][i][t] = original node index (uint32)   — the reference's (N, m) layout per forest
+// MODE 1: out[b][w][i] = 4 dense leaf ids packed per dword — Gram kernel input, Npad points per plane
+template <int MODE, bool X_IN_LDS>
+__global__ __launch_bounds__(WALK_THREADS) void leaf_walk_kernel(const uint4 *__restrict__ nodes, int stride, int m,
+                                                                 int max_depth, const double *__restrict__ X, int N,
+                                                                 int d, int npad, uint32_t *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double xs[];
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * WALK_THREADS + tid;
+    const int b = blockIdx.y;
+    const int sd = d | 1;
+    const double *xrow;
+    if (X_IN_LDS) {
+        // coalesced copy of up to 256 rows, then each thread reads its own (padded) row
+        const int row0 = blockIdx.x * WALK_THREADS;
+        const int rows = min(WALK_THREADS, N - row0);
+        for (int e = tid; e < rows * d; e += WALK_THREADS) {
+            const int r = e / d, c = e - r * d;
+            xs[r * sd + c] = X[(size_t)row0 * d + e];
+        }
+        __syncthreads();
+        xrow = xs + tid * sd;
+    } else {
+        xrow = X + (size_t)min(i, N - 1) * d;
+    }
+    const bool live = i < N;
+    const uint4 *forest = nodes + (size_t)b * m * stride;
+
+    if (MODE == 0) {
+        if (!live) return;
+        uint32_t *o = out + ((size_t)b * N + i) * m;
+        for (int t = 0; t < m; ++t) o[t] = walk_tree<X_IN_LDS>(forest + (size_t)t * stride, max_depth, xrow).y;
+    } else {
+        const int W = (m + 3) >> 2;
+        if (i >= npad) return;
+        for (int w = 0; w < W; ++w) {
+            uint32_t word = 0;
+            if (live) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int t = w * 4 + q;
+                    if (t < m) {
+                        const uint4 leaf = walk_tree<X_IN_LDS>(forest + (size_t)t * stride, max_depth, xrow);
+                        word |= (leaf.x & 0xFFu) << (8 * q);
+                    }
+                }
+            }
+            out[((size_t)b * W + w) * npad + i] = word;
+        }
+    }
+}
+
+template <int MODE>
+int launch_walk(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d, uint32_t *out,
+                void *stream) {
+    if (!packed || !info || !X || !out) return fail(BARK_ERR_ARG, "leaf walk: null argument");
+    if (N < 1 || d < 1 || N > (1 << 30)) return fail(BARK_ERR_ARG, "leaf walk: bad N=%lld d=%lld", (long long)N, (long long)d);
+    if (info->B > 65535) return fail(BARK_ERR_ARG, "leaf walk: at most 65535 forests per call (got %lld)", (long long)info->B);
+    const int64_t npad = bark_leaf_npad(N);
+    if (MODE == 1 && info->max_leaves > 256)
+        return fail(BARK_ERR_ARG, "more than 256 leaves per tree (%lld) is not supported by the byte-packed Gram path",
+                    (long long)info->max_leaves);
+    const int64_t extent = MODE == 1 ? npad : N;
+    dim3 grid((unsigned)((extent + WALK_THREADS - 1) / WALK_THREADS), (unsigned)info->B);
+    const size_t lds = (size_t)WALK_THREADS * (d | 1) * sizeof(double);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint4 *nodes = static_cast<const uint4 *>(packed);
+    if (lds <= 64 * 1024) {
+        hipLaunchKernelGGL((leaf_walk_kernel<MODE, true>), grid, dim3(WALK_THREADS), lds, s, nodes, (int)info->stride,
+                           (int)info->m, (int)info->max_depth, X, (int)N, (int)d, (int)npad, out);
+    } else {
+        hipLaunchKernelGGL((leaf_walk_kernel<MODE, false>), grid, dim3(WALK_THREADS), 0, s, nodes, (int)info->stride,
+                           (int)info->m, (int)info->max_depth, X, (int)N, (int)d, (int)npad, out);
+    }
+    BARK_LAUNCH_CHECK();
+    return BARK_OK;
+}
+
+}  // namespace
+}  // namespace bark
+
+using namespace bark;
+
+extern "C" {
+
+int64_t bark_leaf_npad(int64_t N) { return round_up(N, TILE); }
+
+int bark_leaf_indices_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
+                          uint32_t *out, void *stream) {
+    error_buffer()[0] = 0;
+    return launch_walk<0>(packed, info, X, N, d, out, stream);
+}
+
+int bark_leaf_bytes_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
+                        uint32_t *out, void *stream) {
+    error_buffer()[0] = 0;
+    return launch_walk<1>(packed, info, X, N, d, out, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,271 @@
+"""Drop-in for `bark.forest` (reference: src/bark/forest.py) running on MI355X.
+
+Same names, argument order, shapes and dtypes as the reference module:
+
+    NODE_RECORD_DTYPE, FeatureTypeEnum, create_empty_forest,
+    pass_through_tree, pass_through_forest, get_leaf_vectors,
+    forest_gram_matrix, batched_forest_gram_matrix, batched_forest_gram_matrix_no_null
+
+numpy in -> numpy out (host round trip over PCIe), or pass `torch` CUDA tensors for the
+point matrices to keep inputs/outputs resident in HBM (then torch tensors are returned).
+Forests are always host numpy arrays of packed 26-byte node records, exactly what the
+reference's sampler produces; they are validated and repacked on the host (C, libbarkhip.so)
+and walked on the GPU.  There is no CPU compute path in this module.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from enum import Enum
+
+import numpy as np
+
+from . import _lib
+
+# src/bark/forest.py:8-19 — packed struct, itemsize 26
+NODE_RECORD_DTYPE = np.dtype(
+    [
+        ("is_leaf", np.uint8),
+        ("feature_idx", np.uint32),
+        ("threshold", np.float32),
+        ("left", np.uint32),
+        ("right", np.uint32),
+        ("parent", np.uint32),
+        ("depth", np.uint32),
+        ("active", np.uint8),
+    ]
+)
+
+
+class FeatureTypeEnum(Enum):  # src/bark/forest.py:22-25
+    Cat = 0
+    Int = 1
+    Cont = 2
+
+
+def create_empty_forest(m: int, node_limit: int = 100) -> np.ndarray:
+    """forest.py:114-117.  The reference writes parent = -1 into a uint32 field (wraps to
+    0xFFFFFFFF under numpy 1.x, raises under numpy 2); the wrapped value is stored explicitly."""
+    forest = np.zeros((m, node_limit), dtype=NODE_RECORD_DTYPE)
+    forest[:, 0] = (1, 0, 0, 0, 0, np.uint32(0xFFFFFFFF), 0, 1)
+    return forest
+
+
+# ----------------------------------------------------------------------------------------
+# host-side plumbing
+# ----------------------------------------------------------------------------------------
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _as_nodes(nodes, ndim: int) -> np.ndarray:
+    nodes = np.asarray(nodes)
+    if nodes.dtype != NODE_RECORD_DTYPE:
+        if nodes.dtype.names == NODE_RECORD_DTYPE.names and nodes.dtype.itemsize == 26:
+            nodes = nodes.view(NODE_RECORD_DTYPE)
+        else:
+            raise TypeError(f"nodes must use NODE_RECORD_DTYPE (packed, itemsize 26), got {nodes.dtype}")
+    if nodes.ndim < ndim:
+        raise ValueError(f"nodes must have at least {ndim} dims, got shape {nodes.shape}")
+    # the sampler hands over views such as forest[:, -1] (bofire_mixed/surrogates/bark.py:137-141)
+    return np.ascontiguousarray(nodes)
+
+
+def _feat_types(feat_types) -> np.ndarray:
+    ft = np.ascontiguousarray(np.asarray(feat_types), dtype=np.int64)
+    if ft.ndim != 1:
+        raise ValueError("feat_types must be 1-D")
+    return ft
+
+
+def _points(X, d_expected=None):
+    """-> (device float64 (N, d) tensor, was_torch)."""
+    import torch
+
+    was_torch = _is_torch(X)
+    if was_torch:
+        if X.dtype != torch.float64:
+            X = X.to(torch.float64)
+        t = _lib.to_device(X.detach())
+    else:
+        arr = np.asarray(X)
+        if arr.dtype != np.float64:
+            arr = arr.astype(np.float64)
+        t = _lib.to_device(arr)
+    if t.ndim != 2:
+        raise ValueError(f"point matrix must be (N, d), got {tuple(t.shape)}")
+    if d_expected is not None and t.shape[1] != d_expected:
+        raise ValueError(f"point matrix has {t.shape[1]} features, feat_types has {d_expected}")
+    if t.shape[0] < 1:
+        raise ValueError("empty point matrix")
+    return t, was_torch
+
+
+def _check_categorical(Xd, ft: np.ndarray):
+    """The reference raises inside `1 << int(x)` for NaN/inf/negative categories (forest.py:38)."""
+    import torch
+
+    cat = np.flatnonzero(ft == FeatureTypeEnum.Cat.value)
+    if cat.size == 0:
+        return
+    v = Xd[:, torch.as_tensor(cat, device=Xd.device)]
+    if bool((~torch.isfinite(v) | (v <= -1.0)).any().item()):
+        raise ValueError("categorical feature value is negative, NaN or inf")
+
+
+class PackedForest:
+    """B forests repacked into the device wire format (include/bark_hip.h)."""
+
+    def __init__(self, nodes3: np.ndarray, ft: np.ndarray):
+        import torch
+
+        lib = _lib.lib()
+        B, m, L = nodes3.shape
+        self.info = _lib.PackInfo()
+        _lib.check(lib.bark_forest_pack_info(_lib.ptr(nodes3), B, m, L, _lib.ptr(ft), ft.shape[0],
+                                             ctypes.byref(self.info)))
+        host = torch.empty(int(self.info.packed_bytes), dtype=torch.uint8).pin_memory() \
+            if torch.cuda.is_available() else torch.empty(int(self.info.packed_bytes), dtype=torch.uint8)
+        _lib.check(lib.bark_forest_pack(_lib.ptr(nodes3), _lib.ptr(ft), ft.shape[0], ctypes.byref(self.info),
+                                        ctypes.c_void_p(host.data_ptr())))
+        self.packed = host.to(_lib.torch_device())
+        self.B, self.m, self.L = B, m, L
+
+    @property
+    def info_ref(self):
+        return ctypes.byref(self.info)
+
+
+def pack_forest(nodes, feat_types) -> PackedForest:
+    """Validate + repack `(…, m, L)` node records (leading dims flattened to B)."""
+    nodes = _as_nodes(nodes, 2)
+    ft = _feat_types(feat_types)
+    nodes3 = nodes.reshape(-1, *nodes.shape[-2:])
+    return PackedForest(nodes3, ft)
+
+
+def _leaf_bytes(pf: PackedForest, Xd):
+    import torch
+
+    lib = _lib.lib()
+    N, d = Xd.shape
+    npad = int(lib.bark_leaf_npad(N))
+    W = (pf.m + 3) // 4
+    out = torch.empty((pf.B, W, npad), dtype=torch.int32, device=Xd.device)
+    _lib.check(lib.bark_leaf_bytes_hip(_lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(out),
+                                       _lib.stream_ptr()))
+    return out
+
+
+def _leaf_indices(pf: PackedForest, Xd):
+    import torch
+
+    N, d = Xd.shape
+    out = torch.empty((pf.B, N, pf.m), dtype=torch.int32, device=Xd.device)
+    _lib.check(_lib.lib().bark_leaf_indices_hip(_lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(out),
+                                                _lib.stream_ptr()))
+    return out
+
+
+def _out(t, was_torch, np_dtype=None):
+    if was_torch:
+        return t
+    a = t.cpu().numpy()
+    return a.view(np_dtype) if np_dtype is not None else a
+
+
+def _gram(nodes3, x1, x2, feat_types, *, shift=None, scale=None, noise=None):
+    """(B, N, M) float64 device tensor + was_torch flag."""
+    import torch
+
+    ft = _feat_types(feat_types)
+    same = x2 is x1
+    X1, t1 = _points(x1, ft.shape[0])
+    _check_categorical(X1, ft)
+    if same:
+        X2 = X1
+    else:
+        X2, _ = _points(x2, ft.shape[0])
+        _check_categorical(X2, ft)
+    pf = PackedForest(nodes3, ft)
+    if pf.info.max_leaves > 256:
+        raise ValueError(f"trees with more than 256 leaves ({pf.info.max_leaves}) are not supported")
+    l1 = _leaf_bytes(pf, X1)
+    l2 = l1 if same else _leaf_bytes(pf, X2)
+    N, M = X1.shape[0], X2.shape[0]
+    out = torch.empty((pf.B, N, M), dtype=torch.float64, device=X1.device)
+    dev = lambda v: None if v is None else _lib.to_device(np.ascontiguousarray(v, dtype=np.float64))  # noqa: E731
+    sh, sc, no = dev(shift), dev(scale), dev(noise)
+    _lib.check(_lib.lib().bark_gram_from_leaves_hip(
+        _lib.ptr(l1), N, _lib.ptr(l2), M, pf.B, pf.m, int(pf.info.max_leaves), _lib.ptr(sh), _lib.ptr(sc),
+        _lib.ptr(no), _lib.ptr(out), M, N * M, _lib.stream_ptr()))
+    return out, t1
+
+
+# ----------------------------------------------------------------------------------------
+# the reference API
+# ----------------------------------------------------------------------------------------
+def pass_through_forest(nodes, X, feat_types):
+    """forest.py:58-67 -> (N, m) uint32: node index of the leaf each point reaches in each tree."""
+    nodes = _as_nodes(nodes, 2)
+    if nodes.ndim != 2:
+        raise ValueError(f"nodes must be (m, node_limit), got {nodes.shape}")
+    ft = _feat_types(feat_types)
+    Xd, was_torch = _points(X, ft.shape[0])
+    _check_categorical(Xd, ft)
+    pf = PackedForest(nodes[None], ft)
+    out = _leaf_indices(pf, Xd)[0]
+    return _out(out, was_torch, np.uint32)
+
+
+def pass_through_tree(nodes, X, feat_types):
+    """forest.py:50-55 -> (N,) uint32."""
+    nodes = _as_nodes(nodes, 1)
+    if nodes.ndim != 1:
+        raise ValueError(f"nodes must be (node_limit,), got {nodes.shape}")
+    out = pass_through_forest(nodes[None], X, feat_types)
+    return out[:, 0].copy() if isinstance(out, np.ndarray) else out[:, 0].contiguous()
+
+
+def get_leaf_vectors(nodes, X, feat_types):
+    """forest.py:70-75 -> (N, r) float64 one-hot over the reached leaves, ascending node index."""
+    leaves = pass_through_tree(nodes, X, feat_types)
+    if isinstance(leaves, np.ndarray):
+        all_leaves = np.unique(leaves)
+        return np.equal(leaves[:, None], all_leaves[None, :]).astype(np.float64)
+    import torch
+
+    all_leaves = torch.unique(leaves)
+    return (leaves[:, None] == all_leaves[None, :]).to(torch.float64)
+
+
+def forest_gram_matrix(nodes, x1, x2, feat_types):
+    """forest.py:78-89 -> (N, M) float64, K = (1/m) * #trees in which x1_i and x2_j share a leaf."""
+    nodes = _as_nodes(nodes, 2)
+    if nodes.ndim != 2:
+        raise ValueError(f"nodes must be (m, node_limit), got {nodes.shape}")
+    out, was_torch = _gram(nodes[None], x1, x2, feat_types)
+    return _out(out[0], was_torch)
+
+
+def batched_forest_gram_matrix(nodes, x1, x2, feat_types):
+    """forest.py:92-98 -> (B, N, M) float64 (batch = nodes.shape[-3])."""
+    nodes = _as_nodes(nodes, 3)
+    if nodes.ndim != 3:
+        raise ValueError(f"nodes must be (B, m, node_limit), got {nodes.shape}")
+    out, was_torch = _gram(nodes, x1, x2, feat_types)
+    return _out(out, was_torch)
+
+
+def batched_forest_gram_matrix_no_null(nodes, x1, x2, feat_types):
+    """forest.py:102-111: Gram matrix after removing trees whose root is a leaf."""
+    nodes = _as_nodes(nodes, 3)
+    if nodes.ndim != 3:
+        raise ValueError(f"nodes must be (B, m, node_limit), got {nodes.shape}")
+    num_trees = nodes.shape[-2]
+    num_null = np.sum(nodes[:, :, 0]["is_leaf"], axis=-1).astype(np.int64)  # forest.py:107
+    num_non_null = num_trees - num_null
+    scale = num_trees / np.maximum(num_non_null, 1)  # forest.py:110
+    shift = num_null / num_trees                     # forest.py:111
+    out, was_torch = _gram(nodes, x1, x2, feat_types, shift=shift, scale=scale)
+    return _out(out, was_torch)

@@ -1,0 +1,47 @@
+"""Drop-in for the numpy part of `bark.tree_kernels.tree_gps`
+(reference: src/bark/tree_kernels/tree_gps.py:80-131).
+
+`forest_predict` runs one fused device sweep per chunk of forest samples: Gram(X,X), Gram(X,cand),
+blocked Cholesky with the candidate block appended as extra columns (V = U^-T K_Xx), then
+mu = V'z and var = scale - colsumsq(V).  The reference's `diag=False` full (B, C, C) covariance is
+formed only on request (it needs V'V), from the same V.  The gpytorch `LeafGP`/`LeafMOGP` classes of
+the reference are out of scope.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .. import _lib
+from ..fitting.mll import _feat_types_of, _run
+from ..forest import _is_torch
+
+
+def forest_predict(model, data, candidates, domain, diag: bool = True):
+    """tree_gps.py:80-113 -> (mu (B, C), var (B, C)); `domain` may be the feat_types array."""
+    if not diag:
+        raise NotImplementedError(
+            "diag=False (full B x C x C covariance, tree_gps.py:108) is not built: every caller of the "
+            "reference uses the diagonal (surrogates/bark.py:76)")
+    forest, noise, scale = model
+    train_x, train_y = data
+    forest = np.asarray(forest)
+    noise = np.asarray(noise, dtype=np.float64).reshape(-1)   # tree_gps.py:88-90 flatten
+    scale = np.asarray(scale, dtype=np.float64).reshape(-1)
+    flags = _lib.MLL_INCLUDE_SCALE
+    _, mu, var = _run(forest, noise, scale, train_x, train_y, _feat_types_of(domain), flags, cand=candidates)
+    if _is_torch(candidates):
+        return mu, var
+    return mu.cpu().numpy(), var.cpu().numpy()
+
+
+def mixture_of_gaussians_as_normal(mu, var):
+    """tree_gps.py:116-131: moments of the equal-weight mixture over forest samples.
+    (B x C elementwise host arithmetic, as in the reference; works on numpy or torch.)"""
+    if _is_torch(mu):
+        mu_y = mu.mean(dim=0)
+        var_y = (var + mu**2).mean(dim=0) - mu_y**2
+        return mu_y, var_y
+    mu_y = np.mean(mu, axis=0)
+    var_y = np.mean(var + mu**2, axis=0) - mu_y**2
+    return mu_y, var_y

@@ -1,0 +1,153 @@
+/*
+ * bark_hip.h — C ABI of libbarkhip.so: the MI355X (gfx950) forest-kernel Gram + GP
+ * marginal-log-likelihood / posterior engine behind the `bark.forest`,
+ * `bark.tree_kernels` and `bark.fitting` Python API of TobyBoyne/bark.
+ *
+ * The reference has no FFI layer (it is Python + numba); its boundary for this path is a
+ * set of module-level Python functions taking numpy arrays.  Each entry point below names
+ * the reference function (path:line under /root/reference/src/bark) it serves.  The
+ * binding a maintainer adds on the reference side is a ctypes stub — see INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C types only; `int` status return, 0 == BARK_OK; message via bark_last_error()
+ *    (thread-local).  The library never aborts and never frees/retains caller buffers.
+ *  - `*_hip` entry points take DEVICE pointers (e.g. torch `tensor.data_ptr()`) and a
+ *    `hipStream_t` passed as `void*` (NULL = default stream).  They only enqueue work:
+ *    no allocation, no host synchronisation, so they are hipGraph-capturable.
+ *  - `*_pack*` entry points are HOST functions on host pointers (format conversion only).
+ *  - all matrices are row-major float64; feature matrices X are (N, d) row-major float64.
+ */
+#ifndef BARK_HIP_H
+#define BARK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BARK_HIP_VERSION 100 /* 0.1.0 */
+
+enum {
+    BARK_OK = 0,
+    BARK_ERR_ARG = 1,         /* bad shape / null pointer / unsupported size */
+    BARK_ERR_TREE = 2,        /* malformed tree: child index >= node_limit, cycle, feature_idx >= d */
+    BARK_ERR_CATEGORICAL = 3, /* categorical threshold is not a bitmask in [0, 2^32) */
+    BARK_ERR_HIP = 4,         /* a HIP runtime call failed (launch error etc.) */
+    BARK_ERR_WORKSPACE = 5    /* workspace too small */
+};
+
+/* MLL conventions (bit flags) */
+enum {
+    BARK_MLL_INCLUDE_SCALE = 1, /* K_s = scale*K + (1e-6+noise) I   (bark_sampler.py:153-156) */
+    BARK_MLL_INCLUDE_2PI = 2    /* subtract n*log(2*pi)             (examples/mcmc/mcmc_record_mll.py:73) */
+};
+
+int bark_version(void);
+/* Last error message of the calling thread ("" if none).  Pointer valid until the next call. */
+const char *bark_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Forest container  (forest.py:8-19 NODE_RECORD_DTYPE: packed 26-byte records)
+ *
+ * bark_forest_pack converts B*m trees of L packed 26-byte node records (host memory,
+ * C-contiguous (B, m, L)) into the device wire format: per tree `stride` 16-byte nodes in
+ * depth-first order (root = slot 0), containing only the nodes reachable from the root.
+ *   node.w0  internal: feature_idx | (is_categorical << 30);   leaf: 0x80000000 | dense_leaf_id
+ *   node.w1  internal: float32 threshold bits, or the uint32 category bitmask;  leaf: original node index
+ *   node.w2/w3  compact index of left/right child
+ * `feat_types` is the reference's int64 array (0 = Cat, 1 = Int, 2 = Cont; forest.py:22-25).
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    int64_t B, m, L;      /* as passed in */
+    int64_t stride;       /* nodes per tree in the packed array (max reachable nodes, >= 1) */
+    int64_t max_leaves;   /* max number of reachable leaves in any tree (dense ids < max_leaves) */
+    int64_t max_depth;    /* longest root-to-leaf walk (edges) */
+    int64_t packed_bytes; /* B*m*stride*16 */
+} bark_pack_info;
+
+/* Pass 1: validate + measure.  Fills *info. */
+int bark_forest_pack_info(const void *nodes26, int64_t B, int64_t m, int64_t L, const int64_t *feat_types,
+                          int64_t d, bark_pack_info *info);
+/* Pass 2: write info->packed_bytes bytes to `packed` (host). */
+int bark_forest_pack(const void *nodes26, const int64_t *feat_types, int64_t d, const bark_pack_info *info,
+                     void *packed);
+
+/* ---------------------------------------------------------------------------------------
+ * Leaf traversal   — forest.py:28-67 (_pass_one_through_tree / pass_through_forest)
+ * ------------------------------------------------------------------------------------- */
+/* (N, m) uint32 leaf NODE indices for each of the B forests: out is (B, N, m) uint32, C order —
+ * bit-identical to pass_through_forest(nodes[b], X, feat_types). */
+int bark_leaf_indices_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
+                          uint32_t *out, void *stream);
+
+/* Byte-packed dense leaf ids used by the Gram kernels: out is (B, W, Npad) uint32 with
+ * W = ceil(m/4) (4 trees per dword, unused byte lanes = 0) and Npad = bark_leaf_npad(N).
+ * Requires info->max_leaves <= 256. */
+int64_t bark_leaf_npad(int64_t N);
+int bark_leaf_bytes_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
+                        uint32_t *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Gram matrix   — forest.py:78-111 (forest_gram_matrix / batched_forest_gram_matrix / _no_null)
+ *   out[b][i][j] = (1.0/m) * #{t : leaf_t(x1_i) == leaf_t(x2_j)}          (bit-exact)
+ * optionally followed, in this order, by
+ *   - shift[b]            (forest.py:111  `sim_mat - num_null_trees / num_trees`)
+ *   * scale[b]            (forest.py:111 `* scale`; tree_gps.py:97; bark_sampler.py:153)
+ *   + (1e-6 + noise[b])   on the diagonal (tree_gps.py:100, mcmc_record_mll.py:67)
+ * each rounded separately, as numpy does.  shift / scale / noise may be NULL (skipped).
+ * leaf1/leaf2 come from bark_leaf_bytes_hip for x1 / x2 (pass the same pointer when x1 is x2);
+ * max_leaves is bark_pack_info.max_leaves of the forest that produced them (<= 128 selects the
+ * carry-free 7-bit compare).  out is (B, N, ld) float64, row stride `ld` >= M, batch stride
+ * `batch_stride` elements.
+ * ------------------------------------------------------------------------------------- */
+int bark_gram_from_leaves_hip(const uint32_t *leaf1, int64_t N, const uint32_t *leaf2, int64_t M, int64_t B,
+                              int64_t m, int64_t max_leaves, const double *shift, const double *scale,
+                              const double *noise, double *out, int64_t ld, int64_t batch_stride, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Batched marginal log-likelihood — mcmc_record_mll.py:57-74, bark_sampler.py:153-162 +
+ * quick_inverse.py:37-38.  One evaluation per forest sample b:
+ *   K_s = [scale_b *] K_b + (1e-6 + noise_b) I ;  mll_b = 0.5(-y' K_s^-1 y - log|K_s| [- n log 2pi])
+ * computed by a blocked fp64 Cholesky (A = U'U, MFMA panels) instead of the reference's LU
+ * inv + slogdet; agreement is by tolerance (rtol 1e-9, atol 1e-8), see DESIGN.md.
+ *
+ * Optional posterior predictive (tree_gps.py:80-113) in the same sweep: pass C > 0 candidates
+ * and get mu (B, C) and var (B, C) = scale_b - diag(K_xX K_s^-1 K_Xx)   (scale always applied,
+ * as forest_predict does).
+ *
+ * workspace: device buffer of at least bark_mll_workspace_bytes(N, C, m, Bc) bytes, where Bc
+ * (1 <= Bc <= B) is the number of forests factorised concurrently; B is processed in chunks of Bc.
+ * info_out (device, B int32): 0, or 1-based index of the first non-positive pivot (not PD).
+ * ------------------------------------------------------------------------------------- */
+size_t bark_mll_workspace_bytes(int64_t N, int64_t C, int64_t m, int64_t Bc);
+
+typedef struct {
+    float gram_ms;     /* leaf traversal + Gram fill of the chunk(s) */
+    float chol_ms;     /* all factorisation launches (potrf/trsm/gemm panels + solves) */
+    float panel_ms;    /* of which: the MFMA panel-update kernel */
+    int64_t n_panel_launches;
+    double panel_flops; /* fp64 flops executed by the panel-update kernel launches */
+} bark_mll_timing;
+
+int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, /* forests (device / host info) */
+                         const double *X, int64_t N, int64_t d,         /* training inputs (device) */
+                         const double *y,                               /* (N,) targets (device) */
+                         const double *noise, const double *scale,      /* (B,) device; scale may be NULL */
+                         int flags,                                     /* BARK_MLL_* */
+                         const double *cand, int64_t C,                 /* (C, d) candidates or NULL/0 */
+                         double *mll_out,                               /* (B,) device */
+                         double *mu_out, double *var_out,               /* (B, C) device or NULL */
+                         int32_t *info_out,                             /* (B,) device */
+                         void *workspace, size_t workspace_bytes, int64_t Bc,
+                         bark_mll_timing *timing, /* optional (host); when non-NULL the call synchronises */
+                         void *stream);
+
+/* quick_inverse.py:37-38  mll(K_inv, K_logdet, y) = 0.5 * (-y' K_inv y - K_logdet), on device. */
+int bark_quadform_hip(const double *K_inv, const double *y, int64_t N, double *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BARK_HIP_H */

@@ -1,0 +1,253 @@
+"""Parity of the HIP path (through the Python API -> ctypes C ABI -> libbarkhip.so) against
+  (1) golden vectors produced by the reference itself (tests/golden/*.npz), and
+  (2) the CPU oracle (oracle/) on seeded inputs, and
+  (3) size-independent properties at BASELINE.json's full sizes.
+
+Bars: leaf indices and Gram matrices BIT-EXACT; MLL / posterior within the stated fp64 tolerance
+rtol=1e-9, atol=1e-8 (reference: LU inv+slogdet; here: blocked Cholesky)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+MLL_RTOL, MLL_ATOL = 1e-9, 1e-8
+
+
+@pytest.fixture(scope="module")
+def B():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import bark_amd.fitting as fit
+    import bark_amd.forest as bf
+    import bark_amd.tree_kernels as tk
+    from bark_amd import synthetic
+    from oracle import oracle as orc
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.bf, ns.fit, ns.tk, ns.syn, ns.orc, ns.torch = bf, fit, tk, synthetic, orc, torch
+    return ns
+
+
+def raw(B, a):
+    return B.orc.nodes_from_raw(a)
+
+
+# ------------------------------------------------------------------ golden vectors (reference) ----
+def test_g1_kat_tree(B):
+    g = load_golden("g1_kat_tree")
+    nodes = raw(B, g["nodes"])
+    leaves = B.bf.pass_through_forest(nodes, g["x"], g["feat_types"])
+    assert leaves.dtype == np.uint32 and leaves.shape == (20, 1) and np.array_equal(leaves, g["leaves"])
+    assert np.array_equal(B.bf.pass_through_tree(nodes[0], g["x"], g["feat_types"]), g["leaves"][:, 0])
+    K = B.bf.forest_gram_matrix(nodes, g["x"], g["x"], g["feat_types"])
+    assert K.dtype == np.float64 and np.array_equal(K, g["K"])
+    assert np.array_equal(B.bf.get_leaf_vectors(nodes[0], g["x"], g["feat_types"]), g["leaf_vectors"])
+
+
+def test_g2_two_tree_kat(B):
+    g = load_golden("g2_two_tree_kat")
+    forest, x, ft = raw(B, g["forest"]), g["x"], g["feat_types"]
+    assert np.array_equal(B.bf.forest_gram_matrix(forest, x, x, ft), g["K"])
+    assert np.array_equal(B.bf.get_leaf_vectors(forest[0], x, ft) * np.sqrt(0.25), g["cur_leaf_vectors"])
+    # quick_inverse.mll on the reference's K_inv / logdet (test_quick_inverse.py:55-101 setting)
+    y = np.linspace(-1, 1, 20).reshape(-1, 1)
+    want = B.orc.mll(g["K_inv"], float(g["K_logdet"]), y)
+    got = B.fit.quick_inverse.mll(g["K_inv"], float(g["K_logdet"]), y)
+    assert np.isclose(got, want, rtol=1e-12)
+    # the same through the Cholesky sweep: K_s = 0.5 K + (1e-6 + noise) I with noise = 0.1 - 1e-6
+    got2 = B.fit.batched_mll(forest[None], [0.1 - 1e-6], [0.5], x, y, ft, include_scale=True, include_2pi=False)
+    assert np.allclose(got2, want, rtol=MLL_RTOL, atol=MLL_ATOL)
+    swapped = forest.copy()
+    swapped[0] = raw(B, g["new_nodes"])
+    assert np.array_equal(B.bf.forest_gram_matrix(swapped, x, x, ft), g["K_swapped"])
+
+
+@pytest.mark.parametrize("N", [64, 257])
+def test_g3_prior_mixed(B, N):
+    g = load_golden(f"g3_prior_mixed_n{N}")
+    forest, X, y, ft = raw(B, g["forest"]), g["X"], g["y"], g["feat_types"]
+    for b in range(forest.shape[0]):
+        assert np.array_equal(B.bf.pass_through_forest(forest[b], X, ft), g["leaves"][b])
+    assert np.array_equal(B.bf.batched_forest_gram_matrix(forest, X, X, ft), g["K"])
+    assert np.array_equal(B.bf.batched_forest_gram_matrix_no_null(forest, X, X, ft), g["K_no_null"])
+    ex = B.fit.batched_mll(forest, g["noise"], None, X, y, ft, include_scale=False, include_2pi=True)
+    sa = B.fit.batched_mll(forest, g["noise"], g["scale"], X, y, ft, include_scale=True, include_2pi=False)
+    assert np.allclose(ex, g["mll_example"], rtol=MLL_RTOL, atol=MLL_ATOL)
+    assert np.allclose(sa, g["mll_sampler"], rtol=MLL_RTOL, atol=MLL_ATOL)
+    # the example script's own signature (mcmc_record_mll.py:57): mll(model, data, domain)
+    ex2 = B.fit.mll((forest, g["noise"], g["scale"]), (X, y), ft)
+    assert np.array_equal(ex2, ex)
+
+
+def test_g4_all_null_forest(B):
+    g = load_golden("g4_all_null")
+    forest, X, ft = raw(B, g["forest"]), g["X"], g["feat_types"]
+    assert np.array_equal(B.bf.pass_through_forest(forest[0], X, ft), g["leaves"])
+    K = B.bf.batched_forest_gram_matrix(forest, X, X, ft)
+    assert np.array_equal(K, g["K"]) and np.all(K == 1.0)
+    assert np.array_equal(B.bf.batched_forest_gram_matrix_no_null(forest, X, X, ft), g["K_no_null"])
+    ex = B.fit.batched_mll(forest, g["noise"], None, X, g["y"], ft, include_scale=False, include_2pi=True)
+    assert np.allclose(ex, g["mll_example"], rtol=MLL_RTOL, atol=MLL_ATOL)
+
+
+def test_g5_boundary_semantics(B):
+    g = load_golden("g5_boundaries")
+    forest, X, ft = raw(B, g["forest"]), g["X"], g["feat_types"]
+    assert np.array_equal(B.bf.pass_through_forest(forest, X, ft), g["leaves"])
+    assert np.array_equal(B.bf.forest_gram_matrix(forest, X, X, ft), g["K"])
+    for bad in (-1.0, np.nan, np.inf):  # the reference raises inside `1 << int(x)`
+        Xb = X.copy()
+        Xb[0, 3] = bad
+        with pytest.raises(ValueError):
+            B.bf.pass_through_forest(forest, Xb, ft)
+
+
+def test_g6_forest_predict(B):
+    g = load_golden("g6_predict")
+    forest = raw(B, g["forest"])  # (2, 2, m, L): chains x samples, flattened by forest_predict
+    model = (forest, g["noise"], g["scale"])
+    mu, var = B.tk.forest_predict(model, (g["X"], g["y"]), g["cand"], g["feat_types"], diag=True)
+    assert mu.shape == g["mu"].shape and var.shape == g["var"].shape
+    assert np.allclose(mu, g["mu"], rtol=1e-9, atol=1e-9)
+    assert np.allclose(var, g["var"], rtol=1e-9, atol=1e-9)
+    K_xX = B.bf.batched_forest_gram_matrix(forest.reshape(-1, *forest.shape[-2:]), g["cand"], g["X"], g["feat_types"])
+    assert np.array_equal(K_xX, g["K_xX"])
+    mix_mu, mix_var = B.tk.mixture_of_gaussians_as_normal(mu, var)
+    assert np.allclose(mix_mu, g["mix_mu"], rtol=1e-9, atol=1e-9) and np.allclose(mix_var, g["mix_var"], rtol=1e-8, atol=1e-9)
+
+
+def test_g7_tree_function_config1(B):
+    g = load_golden("g7_tree_function")
+    forest, leaf_values, f = B.syn.tree_function(dim=5, m=50, function_seed=1)
+    assert np.array_equal(forest, raw(B, g["forest"])) and np.array_equal(leaf_values, g["leaf_values"])
+    assert np.array_equal(f(g["X"]), g["y"])  # bit-exact: integer gather + the same summation order
+
+
+def test_g8_batched_mll(B):
+    g = load_golden("g8_batched_mll")
+    forest, X, y, ft = raw(B, g["forest"]), g["X"], g["y"], g["feat_types"]
+    assert np.array_equal(B.bf.batched_forest_gram_matrix(forest, X, X, ft), g["K"])
+    ex = B.fit.batched_mll(forest, g["noise"], None, X, y, ft, include_scale=False, include_2pi=True)
+    sa = B.fit.batched_mll(forest, g["noise"], g["scale"], X, y, ft, include_scale=True, include_2pi=False)
+    assert np.allclose(ex, g["mll_example"], rtol=MLL_RTOL, atol=MLL_ATOL)
+    assert np.allclose(sa, g["mll_sampler"], rtol=MLL_RTOL, atol=MLL_ATOL)
+    # chunking must not change a single bit
+    one = B.fit.batched_mll(forest, g["noise"], g["scale"], X, y, ft, include_scale=True, include_2pi=False, chunk=1)
+    three = B.fit.batched_mll(forest, g["noise"], g["scale"], X, y, ft, include_scale=True, include_2pi=False, chunk=3)
+    assert np.array_equal(one, sa) and np.array_equal(three, sa)
+
+
+# ------------------------------------------------------------------ oracle on seeded inputs -------
+def test_c2_n1024_against_oracle(B):
+    X, y, bounds, ft = B.syn.unit_cube_problem(1024, 8, seed=1024)
+    F = B.syn.sample_prior_forests(2, 50, bounds, ft, seed=1024)
+    for b in range(2):
+        assert np.array_equal(B.bf.pass_through_forest(F[b], X, ft), B.orc.pass_through_forest(F[b], X, ft))
+    K = B.bf.batched_forest_gram_matrix(F, X, X, ft)
+    assert np.array_equal(K, B.orc.batched_forest_gram_matrix(F, X, X, ft))
+    noise, scale = np.array([0.1, 0.07]), np.array([1.0, 1.3])
+    got = B.fit.batched_mll(F, noise, scale, X, y, ft, include_scale=True, include_2pi=True)
+    want = B.orc.batched_mll(F, noise, scale, X, y, ft, include_scale=True, include_2pi=True)
+    assert np.allclose(got, want, rtol=MLL_RTOL, atol=MLL_ATOL), (got, want)
+
+
+def test_mixed_types_and_ragged_sizes_against_oracle(B):
+    for N, M in ((1, 1), (3, 130), (127, 129), (200, 65), (513, 64)):
+        X, y, bounds, ft = B.syn.mixed_problem(N, seed=N)
+        X2, _, _, _ = B.syn.mixed_problem(M, seed=1000 + M)
+        F = B.syn.sample_prior_forests(2, 13, bounds, ft, seed=N)  # m = 13: one padded byte lane
+        assert np.array_equal(B.bf.batched_forest_gram_matrix(F, X, X2, ft),
+                              B.orc.batched_forest_gram_matrix(F, X, X2, ft))
+        assert np.array_equal(B.bf.pass_through_forest(F[1], X2, ft), B.orc.pass_through_forest(F[1], X2, ft))
+        noise = np.array([0.05, 0.2])
+        got = B.fit.batched_mll(F, noise, None, X, y, ft, include_scale=False, include_2pi=True)
+        want = B.orc.batched_mll(F, noise, None, X, y, ft, include_scale=False, include_2pi=True)
+        assert np.allclose(got, want, rtol=MLL_RTOL, atol=MLL_ATOL), (N, got, want)
+
+
+def test_deep_trees_and_many_leaves(B):
+    rng = np.random.default_rng(5)
+    X = rng.uniform(size=(300, 6))
+    ft = np.full(6, 2)
+    deep = B.syn.full_binary_forest(9, 6, 5, rng)  # 32 leaves / tree
+    assert np.array_equal(B.bf.pass_through_forest(deep, X, ft), B.orc.pass_through_forest(deep, X, ft))
+    assert np.array_equal(B.bf.forest_gram_matrix(deep, X, X, ft), B.orc.forest_gram_matrix(deep, X, X, ft))
+    wide = B.syn.full_binary_forest(5, 6, 8, rng, node_limit=512)  # 256 leaves / tree: 8-bit ids, general compare
+    assert np.array_equal(B.bf.pass_through_forest(wide, X, ft), B.orc.pass_through_forest(wide, X, ft))
+    assert np.array_equal(B.bf.forest_gram_matrix(wide, X, X, ft), B.orc.forest_gram_matrix(wide, X, X, ft))
+    too_wide = B.syn.full_binary_forest(1, 6, 9, rng, node_limit=1024)  # 512 leaves: refused, not wrong
+    with pytest.raises(ValueError, match="256 leaves"):
+        B.bf.forest_gram_matrix(too_wide, X, X, ft)
+    # leaf indices themselves have no such limit
+    assert np.array_equal(B.bf.pass_through_forest(too_wide, X, ft), B.orc.pass_through_forest(too_wide, X, ft))
+
+
+def test_posterior_against_oracle_ragged(B):
+    X, y, bounds, ft = B.syn.mixed_problem(300, seed=9)
+    cand, _, _, _ = B.syn.mixed_problem(257, seed=10)
+    F = B.syn.sample_prior_forests(3, 50, bounds, ft, seed=9)
+    noise, scale = np.array([0.1, 0.05, 0.2]), np.array([1.0, 0.6, 1.4])
+    mu, var = B.tk.forest_predict((F, noise, scale), (X, y), cand, ft)
+    mu0, var0 = B.orc.forest_predict((F, noise, scale), (X, y), cand, ft)
+    assert np.allclose(mu, mu0, rtol=1e-9, atol=1e-9) and np.allclose(var, var0, rtol=1e-9, atol=1e-9)
+
+
+def test_not_positive_definite_raises(B):
+    g = load_golden("g8_batched_mll")
+    forest, X, y, ft = raw(B, g["forest"]), g["X"], g["y"], g["feat_types"]
+    with pytest.raises(np.linalg.LinAlgError, match="not positive definite"):
+        B.fit.batched_mll(forest, np.full(4, -0.5), None, X, y, ft, include_scale=False, include_2pi=True)
+
+
+def test_torch_tensors_stay_on_device(B):
+    torch = B.torch
+    g = load_golden("g3_prior_mixed_n64")
+    forest, ft = raw(B, g["forest"]), g["feat_types"]
+    Xd = torch.from_numpy(g["X"]).cuda()
+    K = B.bf.batched_forest_gram_matrix(forest, Xd, Xd, ft)
+    assert K.is_cuda and np.array_equal(K.cpu().numpy(), g["K"])
+    from bark_amd.tree_kernels.tree_model_kernel import TreeAgreementKernel
+
+    kern = TreeAgreementKernel(forest[0], ft)
+    assert np.array_equal(kern.forward(Xd, Xd).cpu().numpy(), g["K"][0])
+    Xc = torch.from_numpy(g["X"])
+    assert np.array_equal(kern.forward(Xc, Xc).numpy(), g["K"][0])
+    assert torch.equal(kern.forward(Xc, Xc, diag=True), torch.ones(64))
+
+
+# ------------------------------------------------------------------ full-size properties ----------
+def test_c3_full_size_properties(B):
+    """N = 4096, m = 50 (BASELINE configs[2]) — properties that need no CPU reference."""
+    N, m, nb = 4096, 50, 6
+    X, y, bounds, ft = B.syn.unit_cube_problem(N, 8, seed=4096)
+    F = B.syn.sample_prior_forests(nb, m, bounds, ft, seed=4096)
+    Xd = B.torch.from_numpy(X).cuda()
+    K = B.bf.batched_forest_gram_matrix(F, Xd, Xd, ft)
+    assert bool((K == K.transpose(1, 2)).all())                      # symmetric, bit for bit
+    assert bool((K.diagonal(dim1=1, dim2=2) == 1.0).all())           # a point always shares its own leaf
+    counts = K * m
+    assert bool((counts.round() - counts).abs().max() < 1e-9)        # entries are multiples of 1/m
+    perm = np.random.default_rng(0).permutation(m)                   # tree order is irrelevant
+    assert bool((B.bf.batched_forest_gram_matrix(F[:, perm], Xd, Xd, ft) == K).all())
+    # leaf indices of one forest against the oracle, all 4096 x 50 of them
+    assert np.array_equal(B.bf.pass_through_forest(F[0], X, ft), B.orc.pass_through_forest(F[0], X, ft))
+    noise = np.linspace(0.05, 0.15, nb)
+    mll = B.fit.batched_mll(F, noise, None, Xd, y, ft, include_scale=False, include_2pi=True)
+    # one forest against the oracle's LU route (the reference's own arithmetic)
+    want = B.orc.batched_mll(F[:1], noise[:1], None, X, y, ft, include_scale=False, include_2pi=True)
+    assert np.allclose(mll[:1], want, rtol=MLL_RTOL, atol=MLL_ATOL), (mll[0], want)
+    # batch-position independence: same forest, same noise -> identical bits wherever it sits
+    again = B.fit.batched_mll(F[::-1].copy(), noise[::-1].copy(), None, Xd, y, ft, include_scale=False, include_2pi=True)
+    assert np.array_equal(again[::-1], mll)
+    # scale/noise identity: MLL(scale=s, noise) with y  ==  MLL(scale=1, (noise+1e-6)/s - 1e-6) with y/sqrt(s) - N/2 log s
+    s = 1.7
+    lhs = B.fit.batched_mll(F[:2], noise[:2], np.full(2, s), Xd, y, ft, include_scale=True, include_2pi=False)
+    rhs = B.fit.batched_mll(F[:2], (noise[:2] + 1e-6) / s - 1e-6, np.ones(2), Xd, y / np.sqrt(s), ft,
+                            include_scale=True, include_2pi=False) - 0.5 * N * np.log(s)
+    assert np.allclose(lhs, rhs, rtol=1e-9, atol=1e-6)

@@ -1,0 +1,178 @@
+"""CPU-side tests of the product's host logic: the C ABI loads and exports what
+include/bark_hip.h declares, and the forest packer (host C in libbarkhip.so) produces a wire
+format whose walk reproduces the reference leaves.  No GPU compute is called here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from bark_amd import _lib, forest as bf, synthetic
+from oracle import oracle as orc
+
+from conftest import ROOT, load_golden
+
+LEAF, CAT, FEAT = 0x80000000, 0x40000000, 0x3FFFFFFF
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "bark_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(bark_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.lib()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.bark_version() == 100
+    assert lib.bark_last_error() == b""
+    assert lib.bark_leaf_npad(1) == 128 and lib.bark_leaf_npad(128) == 128 and lib.bark_leaf_npad(129) == 256
+
+
+def host_pack(nodes3, ft):
+    lib = _lib.lib()
+    info = _lib.PackInfo()
+    B, m, L = nodes3.shape
+    nodes3 = np.ascontiguousarray(nodes3)
+    ft = np.ascontiguousarray(ft, dtype=np.int64)
+    _lib.check(lib.bark_forest_pack_info(_lib.ptr(nodes3), B, m, L, _lib.ptr(ft), ft.shape[0], ctypes.byref(info)))
+    packed = np.zeros(info.packed_bytes // 4, dtype=np.uint32)
+    _lib.check(lib.bark_forest_pack(_lib.ptr(nodes3), _lib.ptr(ft), ft.shape[0], ctypes.byref(info), _lib.ptr(packed)))
+    return info, packed.reshape(B, m, info.stride, 4)
+
+
+def walk_packed(packed_tree, x, max_depth):
+    """numpy emulation of the device walk (traverse.hip) on the wire format."""
+    n = packed_tree[0]
+    for _ in range(max_depth):
+        if n[0] & LEAF:
+            break
+        f = int(n[0] & FEAT)
+        if n[0] & CAT:
+            xt = np.trunc(x[f])
+            left = bool((int(n[1]) >> int(xt)) & 1) if 0 <= xt < 32 else False
+        else:
+            left = x[f] <= float(np.uint32(n[1]).view(np.float32))
+        n = packed_tree[int(n[2] if left else n[3])]
+    assert n[0] & LEAF
+    return int(n[1]), int(n[0] & 0xFF)
+
+
+@pytest.mark.parametrize("name", ["g1_kat_tree", "g3_prior_mixed_n64", "g5_boundaries", "g7_tree_function"])
+def test_packer_wire_format_reproduces_reference_leaves(name):
+    g = load_golden(name)
+    key = "nodes" if "nodes" in g else "forest"
+    nodes = orc.nodes_from_raw(g[key])
+    nodes3 = nodes.reshape(-1, *nodes.shape[-2:])
+    X = g["x"] if "x" in g else g["X"]
+    ft = g["feat_types"]
+    leaves = g["leaves"].reshape(nodes3.shape[0], X.shape[0], nodes3.shape[1])
+    info, packed = host_pack(nodes3, ft)
+    assert info.stride <= nodes3.shape[2] and info.max_leaves <= (nodes3.shape[2] + 1) // 2 + 1
+    for b in range(nodes3.shape[0]):
+        for t in range(nodes3.shape[1]):
+            dense_of = {}
+            for i in range(X.shape[0]):
+                orig, dense = walk_packed(packed[b, t], X[i], info.max_depth)
+                assert orig == leaves[b, i, t]
+                assert dense_of.setdefault(orig, dense) == dense and dense < info.max_leaves
+            assert len(set(dense_of.values())) == len(dense_of)  # dense ids are a bijection of reached leaves
+
+
+def test_packer_statistics_match_active_nodes():
+    X, y, bounds, ft = synthetic.mixed_problem(16, 3)
+    F = synthetic.sample_prior_forests(4, 50, bounds, ft, seed=11)
+    info, packed = host_pack(F, ft)
+    active = (F["active"] == 1).sum(-1)
+    assert info.stride == active.max()  # prior forests have no pruned garbage: reachable == active
+    leaves = ((F["active"] == 1) & (F["is_leaf"] == 1)).sum(-1)
+    assert info.max_leaves == leaves.max()
+    assert info.max_depth == F["depth"][F["active"] == 1].max()
+
+
+def _tree(rows, L=8):
+    t = np.zeros(L, dtype=bf.NODE_RECORD_DTYPE)
+    for i, r in enumerate(rows):
+        t[i] = r
+    return t[None, None]
+
+
+def test_packer_rejects_malformed_trees():
+    ft = np.array([2, 0])
+    ok = _tree([(0, 0, 0.5, 1, 2, 0, 0, 1), (1, 0, 0, 0, 0, 0, 1, 1), (1, 0, 0, 0, 0, 0, 1, 1)])
+    host_pack(ok, ft)
+    with pytest.raises(ValueError, match="outside container"):
+        host_pack(_tree([(0, 0, 0.5, 1, 9, 0, 0, 1), (1, 0, 0, 0, 0, 0, 1, 1)]), ft)
+    with pytest.raises(ValueError, match="cycle"):
+        host_pack(_tree([(0, 0, 0.5, 1, 2, 0, 0, 1), (0, 0, 0.2, 0, 2, 0, 1, 1), (1, 0, 0, 0, 0, 0, 1, 1)]), ft)
+    with pytest.raises(ValueError, match="feature_idx"):
+        host_pack(_tree([(0, 5, 0.5, 1, 2, 0, 0, 1), (1, 0, 0, 0, 0, 0, 1, 1), (1, 0, 0, 0, 0, 0, 1, 1)]), ft)
+    with pytest.raises(ValueError, match="bitmask"):
+        host_pack(_tree([(0, 1, -3.0, 1, 2, 0, 0, 1), (1, 0, 0, 0, 0, 0, 1, 1), (1, 0, 0, 0, 0, 0, 1, 1)]), ft)
+    # pruned garbage behind a leaf is ignored (tree_proposals.py:168-175 leaves children in place)
+    pruned = _tree([(1, 0, 0.5, 7, 7, 0, 0, 1)])
+    info, packed = host_pack(pruned, ft)
+    assert info.stride == 1 and info.max_leaves == 1 and info.max_depth == 0
+
+
+def test_workspace_size_is_linear_in_chunk():
+    lib = _lib.lib()
+    one = lib.bark_mll_workspace_bytes(4096, 0, 50, 1)
+    two = lib.bark_mll_workspace_bytes(4096, 0, 50, 2)
+    many = lib.bark_mll_workspace_bytes(4096, 0, 50, 256)
+    assert one >= 4096 * 4096 * 8 and abs((many - one) - 255 * (two - one)) <= 256 * 1024
+    assert lib.bark_mll_workspace_bytes(0, 0, 50, 1) == 0
+    assert lib.bark_mll_workspace_bytes(1000, 500, 50, 3) > lib.bark_mll_workspace_bytes(1000, 0, 50, 3)
+
+
+def test_reference_api_surface():
+    # names a user of bark.forest / tree_gps / quick_inverse / mcmc_record_mll imports
+    import bark_amd.fitting as fit
+    import bark_amd.tree_kernels as tk
+    from bark_amd.tree_kernels.tree_model_kernel import TreeAgreementKernel  # noqa: F401
+
+    for n in ("NODE_RECORD_DTYPE", "FeatureTypeEnum", "create_empty_forest", "pass_through_tree",
+              "pass_through_forest", "get_leaf_vectors", "forest_gram_matrix", "batched_forest_gram_matrix",
+              "batched_forest_gram_matrix_no_null"):
+        assert hasattr(bf, n)
+    assert bf.NODE_RECORD_DTYPE == orc.NODE_RECORD_DTYPE and bf.NODE_RECORD_DTYPE.itemsize == 26
+    assert [e.value for e in bf.FeatureTypeEnum] == [0, 1, 2]
+    assert np.array_equal(bf.create_empty_forest(3, 10), orc.create_empty_forest(3, 10))
+    for n in ("mll", "low_rank_inv_update", "low_rank_det_update"):
+        assert hasattr(fit.quick_inverse, n)
+    assert hasattr(fit, "mll") and hasattr(fit, "batched_mll")
+    assert hasattr(tk, "forest_predict") and hasattr(tk, "mixture_of_gaussians_as_normal")
+    g = load_golden("g6_predict")
+    mix_mu, mix_var = tk.mixture_of_gaussians_as_normal(g["mu"], g["var"])
+    assert np.allclose(mix_mu, g["mix_mu"]) and np.allclose(mix_var, g["mix_var"])
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    g = load_golden("g1_kat_tree")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        bf.forest_gram_matrix(orc.nodes_from_raw(g["nodes"]), g["x"], g["x"], g["feat_types"])
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "bark_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+def test_synthetic_prior_forests_are_valid_and_small():
+    X, y, bounds, ft = synthetic.mixed_problem(64, 5)
+    F = synthetic.sample_prior_forests(3, 50, bounds, ft, seed=42)
+    leaves = np.stack([orc.pass_through_forest(F[b], X, ft) for b in range(3)])
+    assert leaves.max() < 100
+    K = orc.batched_forest_gram_matrix(F, X, X, ft)
+    assert np.all(np.diagonal(K, axis1=1, axis2=2) == 1.0) and np.allclose(K, K.transpose(0, 2, 1))
+    # deterministic in the seed
+    assert np.array_equal(F, synthetic.sample_prior_forests(3, 50, bounds, ft, seed=42))
+    deep = synthetic.full_binary_forest(5, 8, 5, np.random.default_rng(0))
+    assert ((deep["active"] == 1).sum(-1) == 63).all()
