@@ -63,6 +63,10 @@ def lib():
     if _lib is None:
         with _lock:
             if _lib is None:
+                # torch bundles its own HIP runtime; it must be in the process before libbarkhip.so
+                # resolves libamdhip64, or two runtimes get loaded and the second sees no device.
+                import torch  # noqa: F401
+
                 if not os.path.exists(LIB_PATH):
                     raise RuntimeError(
                         f"{LIB_PATH} is missing: build it with `make -C bark_amd/csrc` "

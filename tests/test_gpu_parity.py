@@ -160,6 +160,8 @@ def test_c2_n1024_against_oracle(B):
 def test_mixed_types_and_ragged_sizes_against_oracle(B):
     for N, M in ((1, 1), (3, 130), (127, 129), (200, 65), (513, 64)):
         X, y, bounds, ft = B.syn.mixed_problem(N, seed=N)
+        if N == 1:
+            y = np.array([[0.3]])  # a single point cannot be standardised
         X2, _, _, _ = B.syn.mixed_problem(M, seed=1000 + M)
         F = B.syn.sample_prior_forests(2, 13, bounds, ft, seed=N)  # m = 13: one padded byte lane
         assert np.array_equal(B.bf.batched_forest_gram_matrix(F, X, X2, ft),
