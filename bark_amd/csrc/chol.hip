@@ -49,7 +49,6 @@ constexpr int LDS_LD = NB + 16;  // padded row (doubles)
 constexpr int STAGE = 2 * BK * LDS_LD;  // A rows then B rows, doubles
 constexpr int GEMM_LDS_DOUBLES = 2 * STAGE;
 constexpr int THREADS = 256;
-constexpr int SS = NB + 1;  // row stride of the 128x128 factor image in LDS
 
 struct Lane {
     int wr, wc, lr, lk;
@@ -145,6 +144,20 @@ __device__ __forceinline__ void gemm_kmajor(f64x4 (&acc)[4][4], const double *__
     }
 }
 
+// Workgroup -> (matrix, tile) map for the panel/solve grids.  Blocks are dealt round-robin over the 8
+// XCDs (id % 8 labels the XCD group; speed only, never correctness), and every tile of block row j of
+// one matrix streams the same A panel U[0:128j, j]: give all tiles of matrix b ids == b (mod 8), in one
+// contiguous run of the per-XCD sequence, so that panel is fetched into ONE 4 MiB L2 once and shared.
+// Grid = 8 * ceil(Bc/8) * ntiles; ids whose matrix is >= Bc exit.
+constexpr int NXCD = 8;
+__device__ __forceinline__ bool xcd_map(int id, int ntiles, int Bc, int &b, int &tile) {
+    const int x = id % NXCD, q = id / NXCD;
+    b = (q / ntiles) * NXCD + x;
+    tile = q % ntiles;
+    return b < Bc;
+}
+inline unsigned xcd_grid(int ntiles, int Bc) { return (unsigned)(NXCD * ((Bc + NXCD - 1) / NXCD) * ntiles); }
+
 struct Mats {
     double *A;            // (Bc, Npad, ld)
     long ld, bstride;
@@ -154,15 +167,88 @@ struct Mats {
     int32_t *info;        // (Bc,)
     int nrb;              // row blocks  (Npad / 128)
     int ncb;              // column blocks incl. candidate blocks
+    int Bc;               // matrices in this chunk
 };
 
 // ---------------------------------------------------------------------------------------------
-// diag_kernel: factor + invert the j-th diagonal block of every matrix of the chunk.
+// diag_kernel: factor + invert the j-th diagonal block (128x128) of every matrix of the chunk.
+//
+// Blocked in 16x16 sub-blocks held in one LDS image S[128][SD] (upper block triangle used):
+//   for kb = 0..7:   (A) wave 0 eliminates the 16x16 diagonal sub-block in registers (one element
+//                        column per lane, rows broadcast by ds_bpermute shuffles, no barriers) on
+//                        the augmented [D | I], giving W_kk = U_kk^-1 directly and the pivots;
+//                    (B) U[kb,cb] = W_kk' D[kb,cb]            (one 16x16x16 MFMA chain per block)
+//                    (C) D[rb,cb] -= U[kb,rb]' U[kb,cb]       (one chain per trailing block)
+//   then the block inverse X = U^-1 in place, column block by column block:
+//                        X[rb,jb] = -(sum_{rb<=k<jb} X[rb,k] U[k,jb]) W_jj
+// 3 barriers per kb + 2 per jb instead of ~5 per scalar column.
 // ---------------------------------------------------------------------------------------------
+constexpr int SD = NB + 8;      // row stride of S (doubles): 16-byte aligned rows, 2-way worst-case banks
+constexpr int SB = 16;          // sub-block edge
+constexpr int NSB = NB / SB;    // 8 sub-blocks per edge
+constexpr int TS = SB + 1;      // row stride of the per-wave 16x16 transpose scratch
+
+// acc(16x16) += X' Y for two sub-blocks stored "k-major" (X[k][i], Y[k][j]) with row strides ldx, ldy
+__device__ __forceinline__ void mfma_tn(f64x4 &acc, const double *X, int ldx, const double *Y, int ldy, int lr, int lk) {
+#pragma unroll
+    for (int kk = 0; kk < SB / 4; ++kk)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[(kk * 4 + lk) * ldx + lr], Y[(kk * 4 + lk) * ldy + lr], acc, 0, 0, 0);
+}
+// acc(16x16) += X Y with X stored row-major (X[i][k]) and Y k-major (Y[k][j])
+__device__ __forceinline__ void mfma_nn(f64x4 &acc, const double *X, int ldx, const double *Y, int ldy, int lr, int lk) {
+#pragma unroll
+    for (int kk = 0; kk < SB / 4; ++kk)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[lr * ldx + kk * 4 + lk], Y[(kk * 4 + lk) * ldy + lr], acc, 0, 0, 0);
+}
+
+// (A): one wave eliminates the 16x16 diagonal sub-block `blk` (row stride SD) of S in registers and
+// overwrites it with W = U_kk^-1 (upper triangular, row-major).  Lane (g = l>>4, c = l&15) owns
+// rows g, g+4, g+8, g+12 of column c of [D | I].  Returns sum log(pivot) and the first bad pivot.
+__device__ __forceinline__ void factor16(double *blk, int lane, int base_index, double &logsum, int &bad) {
+    const int c = lane & 15, g = lane >> 4;
+    double e[4], f[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        e[v] = blk[(g + 4 * v) * SD + c];
+        f[v] = (g + 4 * v == c) ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < SB; ++k) {
+        const int kv = k >> 2, kl = (k & 3) * 16;  // row k lives in register kv of lane group k&3
+        double d = __shfl(e[kv], kl + k);
+        if (!(d > 0.0)) {  // not positive definite / NaN: flag once, continue finite
+            if (!bad) bad = base_index + k + 1;
+            d = 1.0;
+        }
+        logsum += 0.5 * log(d);
+        const double rd = 1.0 / d;
+        const double lc = __shfl(e[kv], kl + c);  // D[k][c]
+        const double rc = __shfl(f[kv], kl + c);  // I[k][c]
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = g + 4 * v;
+            const double m = __shfl(e[kv], kl + r) * rd;  // D[k][r] / d   (symmetric: == D[r][k] / d)
+            if (r > k) {
+                e[v] = fma(-m, lc, e[v]);
+                f[v] = fma(-m, rc, f[v]);
+            }
+        }
+    }
+    // row r of the right half is (L~^-1)[r][:]; U^-T = diag(1/sqrt d) L~^-1, so W[c][r] = f * rsqrt(d_r)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int r = g + 4 * v;
+        double dr = __shfl(e[v], g * 16 + r);  // frozen pivot of row r: lane (g, c == r), same register
+        if (!(dr > 0.0)) dr = 1.0;
+        blk[c * SD + r] = f[v] / sqrt(dr);
+    }
+}
+
 __global__ __launch_bounds__(THREADS) void diag_kernel(Mats p, int j) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, b = blockIdx.x;
     const Lane q = lane_of(tid);
+    const int wave = tid >> 6, lane = tid & 63;
     double *Ab = p.A + (size_t)b * p.bstride;
     double *tile = Ab + (size_t)j * NB * p.ld + (size_t)j * NB;
 
@@ -172,10 +258,10 @@ __global__ __launch_bounds__(THREADS) void diag_kernel(Mats p, int j) {
         const double *prev = Ab + (size_t)(j - 1) * NB * p.ld + (size_t)j * NB;  // U[j-1, j]
         gemm_kmajor(acc, prev, p.ld, prev, p.ld, NB, lds, tid, q);
     }
-    double *S = lds;                 // [128][129]
-    double *urow = lds + NB * SS;    // [128]
-    double *tmp = urow + NB;         // [128]
-    double *psum = tmp + NB;         // [2][128]
+    double *S = lds;                              // [128][SD]
+    double *scratch = lds + NB * SD + wave * SB * TS;  // per-wave [16][TS]
+    double *vec = lds + NB * SD + 4 * SB * TS;    // [128] y / partial sums
+    double *red = vec + NB;                       // [8]
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -183,49 +269,65 @@ __global__ __launch_bounds__(THREADS) void diag_kernel(Mats p, int j) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int r = acc_row(q, mt, v), c = acc_col(q, nt);
-                S[r * SS + c] = tile[(size_t)r * p.ld + c] - acc[mt][nt][v];
+                S[r * SD + c] = tile[(size_t)r * p.ld + c] - acc[mt][nt][v];
             }
     __syncthreads();
 
-    // --- unblocked right-looking Cholesky of the upper triangle (D = U'U) in LDS ---------------
-    const int c = tid & (NB - 1), h = tid >> 7;
+    // --- blocked Cholesky D = U'U; diagonal sub-blocks end up holding W_kk = U_kk^-1 -------------
     double logsum = 0.0;
     int bad = 0;
-    for (int k = 0; k < NB; ++k) {
-        double d = S[k * SS + k];
-        if (!(d > 0.0)) {  // not positive definite (or NaN): flag the first pivot, keep going finite
-            if (!bad) bad = k + 1;
-            d = 1.0;
-        }
-        const double piv = sqrt(d);
-        if (h == 0 && c > k) urow[c] = S[k * SS + c] / piv;
-        if (tid == 0) logsum += log(piv);
+    const int lr = q.lr, lk = q.lk;
+    for (int kb = 0; kb < NSB; ++kb) {
+        double *rowk = S + kb * SB * SD;  // sub-block row kb
+        if (wave == 0) factor16(rowk + kb * SB, lane, kb * SB, logsum, bad);
         __syncthreads();
-        if (c > k) {
-            const double ukc = urow[c];
-            for (int r = k + 1 + h; r <= c; r += 2) S[r * SS + c] = fma(-urow[r], ukc, S[r * SS + c]);
-            if (h == 0) S[k * SS + c] = ukc;
-        } else if (c == k && h == 0) {
-            S[k * SS + k] = piv;
+        for (int cb = kb + 1 + wave; cb < NSB; cb += 4) {  // (B)
+            f64x4 u = {0.0, 0.0, 0.0, 0.0};
+            mfma_tn(u, rowk + kb * SB, SD, rowk + cb * SB, SD, lr, lk);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) rowk[(lk + 4 * v) * SD + cb * SB + lr] = u[v];
         }
+        __syncthreads();
+        int pair = 0;
+        for (int rb = kb + 1; rb < NSB; ++rb)  // (C)
+            for (int cb = rb; cb < NSB; ++cb, ++pair) {
+                if ((pair & 3) != wave) continue;
+                f64x4 u = {0.0, 0.0, 0.0, 0.0};
+                mfma_tn(u, rowk + rb * SB, SD, rowk + cb * SB, SD, lr, lk);
+                double *dst = S + rb * SB * SD + cb * SB;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) dst[(lk + 4 * v) * SD + lr] -= u[v];
+            }
         __syncthreads();
     }
 
-    // --- in-place inverse of the upper-triangular factor (column sweep, LAPACK dtrti2 order) ---
-    for (int jj = 0; jj < NB; ++jj) {
-        if (tid < jj) tmp[tid] = S[tid * SS + jj];
-        const double dinv = 1.0 / S[jj * SS + jj];
-        __syncthreads();
-        if (c < jj) {
-            const int mid = (c + jj + 1) >> 1;
-            const int lo = h ? mid : c, hi = h ? jj : mid;
-            double s = 0.0;
-            for (int l = lo; l < hi; ++l) s = fma(S[c * SS + l], tmp[l], s);
-            psum[h * NB + c] = s;
+    // --- X = U^-1 in place (upper block triangle of S) -------------------------------------------
+    for (int jb = 1; jb < NSB; ++jb) {
+        f64x4 t[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int rb = wave + 4 * s;
+            if (rb < jb)
+                for (int k = rb; k < jb; ++k)
+                    mfma_nn(t[s], S + rb * SB * SD + k * SB, SD, S + k * SB * SD + jb * SB, SD, lr, lk);
         }
-        __syncthreads();
-        if (tid < jj) S[tid * SS + jj] = -dinv * (psum[tid] + psum[NB + tid]);
-        if (tid == jj) S[jj * SS + jj] = dinv;
+        __syncthreads();  // every product that reads U[:, jb] is done before the column is overwritten
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int rb = wave + 4 * s;
+            if (rb < jb) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) scratch[(lk + 4 * v) * TS + lr] = t[s][v];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                f64x4 x = {0.0, 0.0, 0.0, 0.0};
+                mfma_nn(x, scratch, TS, S + jb * SB * SD + jb * SB, SD, lr, lk);
+                double *dst = S + rb * SB * SD + jb * SB;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) dst[(lk + 4 * v) * SD + lr] = -x[v];
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
         __syncthreads();
     }
 
@@ -233,26 +335,26 @@ __global__ __launch_bounds__(THREADS) void diag_kernel(Mats p, int j) {
     double *Wb = p.W + (size_t)b * NB * NB;
     for (int e = tid; e < NB * NB; e += THREADS) {
         const int r = e >> 7, cc = e & (NB - 1);
-        Wb[e] = (r <= cc) ? S[r * SS + cc] : 0.0;
+        Wb[e] = (r <= cc) ? S[r * SD + cc] : 0.0;
     }
 
     // --- z_j = W_j' y_j ; quad += |z_j|^2 ; logdet += 2 sum log u_kk ----------------------------
     double *yb = p.yz + (size_t)b * p.nrb * NB + (size_t)j * NB;
-    if (tid < NB) urow[tid] = yb[tid];
+    if (tid < NB) vec[tid] = yb[tid];
     __syncthreads();
     double zz = 0.0;
     if (tid < NB) {
         double z = 0.0;
-        for (int r = 0; r <= tid; ++r) z = fma(S[r * SS + tid], urow[r], z);
+        for (int r = 0; r <= tid; ++r) z = fma(S[r * SD + tid], vec[r], z);
         yb[tid] = z;
         zz = z * z;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) zz += __shfl_xor(zz, off);
-    if ((tid & 63) == 0) psum[tid >> 6] = zz;
+    if (lane == 0) red[wave] = zz;
     __syncthreads();
-    if (tid == 0) {
-        p.accum[(size_t)b * 2 + 0] += psum[0] + psum[1];
+    if (tid == 0) {  // wave 0 ran factor16: its logsum / bad are the matrix's
+        p.accum[(size_t)b * 2 + 0] += red[0] + red[1];
         p.accum[(size_t)b * 2 + 1] += 2.0 * logsum;
         if (bad && p.info[b] == 0) p.info[b] = j * NB + bad;
     }
@@ -260,17 +362,19 @@ __global__ __launch_bounds__(THREADS) void diag_kernel(Mats p, int j) {
 
 // ---------------------------------------------------------------------------------------------
 // panel_kernel: T[j,i] = A[j,i] - sum_{k<j} U[k,j]' U[k,i]  for i > j (all column blocks), and the
-// partial diagonal tile (j+1, j+1).  blockIdx.x = tile, blockIdx.y = matrix.
+// partial diagonal tile (j+1, j+1).  1-D grid, (matrix, tile) from xcd_map.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(THREADS, 2) void panel_kernel(Mats p, int j, int n_right) {
+__global__ __launch_bounds__(THREADS, 2) void panel_kernel(Mats p, int j, int n_right, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int tid = threadIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x;
+    int b, t;
+    if (!xcd_map(blockIdx.x, n_tiles, p.Bc, b, t)) return;
     const Lane q = lane_of(tid);
     double *Ab = p.A + (size_t)b * p.bstride;
     int rb, cb;
-    if ((int)blockIdx.x < n_right) {
+    if (t < n_right) {
         rb = j;
-        cb = j + 1 + blockIdx.x;
+        cb = j + 1 + t;
     } else {
         rb = cb = j + 1;
     }
@@ -294,11 +398,13 @@ __global__ __launch_bounds__(THREADS, 2) void panel_kernel(Mats p, int j, int n_
 // ---------------------------------------------------------------------------------------------
 // solve_kernel: U[j,i] = W_j' T[j,i] for every tile right of the diagonal; y_i -= U[j,i]' z_j.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(THREADS, 2) void solve_kernel(Mats p, int j) {
+__global__ __launch_bounds__(THREADS, 2) void solve_kernel(Mats p, int j, int n_right) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int tid = threadIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x;
+    int b, t;
+    if (!xcd_map(blockIdx.x, n_right, p.Bc, b, t)) return;
     const Lane q = lane_of(tid);
-    const int cb = j + 1 + blockIdx.x;
+    const int cb = j + 1 + t;
     double *Ab = p.A + (size_t)b * p.bstride;
     double *tile = Ab + (size_t)j * NB * p.ld + (size_t)cb * NB;
     const double *Wb = p.W + (size_t)b * NB * NB;
@@ -432,7 +538,7 @@ Layout make_layout(int64_t N, int64_t C, int64_t m, int64_t Bc) {
     return L;
 }
 
-constexpr size_t DIAG_LDS = (size_t)(NB * SS + 4 * NB) * sizeof(double);
+constexpr size_t DIAG_LDS = (size_t)(NB * SD + 4 * SB * TS + NB + 8) * sizeof(double);
 constexpr size_t GEMM_LDS = (size_t)GEMM_LDS_DOUBLES * sizeof(double);
 static_assert(DIAG_LDS >= GEMM_LDS, "diag kernel reuses its LDS for the K=128 GEMM stage");
 
@@ -501,7 +607,7 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
     const bool seven = info->max_leaves <= 128;
     const bool use_scale = (flags & BARK_MLL_INCLUDE_SCALE) != 0;
 
-    std::vector<hipEvent_t> ev;  // timing mode only: [gram0, gram1/chol0, chol1] per chunk + 2 per panel launch
+    std::vector<hipEvent_t> ev;  // timing mode only: chunk marks + one event pair per factorisation launch
     auto mark = [&]() -> int {
         if (!timing) return BARK_OK;
         hipEvent_t e;
@@ -510,9 +616,8 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
         ev.push_back(e);
         return BARK_OK;
     };
-    std::vector<size_t> gram_marks, chol_marks, panel_marks;
-    double panel_flops = 0.0;
-    int64_t panel_launches = 0;
+    std::vector<size_t> gram_marks, chol_marks, diag_marks, panel_marks, solve_marks;
+    double panel_flops = 0.0, solve_flops = 0.0;
 
     for (int64_t c0 = 0; c0 < B; c0 += Bc) {
         const int64_t bc = (B - c0 < Bc) ? (B - c0) : Bc;
@@ -520,6 +625,7 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
         sub.B = bc;
         const char *packed_c = static_cast<const char *>(packed) + (size_t)c0 * m * info->stride * 16;
         p.info = info_out + c0;
+        p.Bc = (int)bc;
 
         if (timing) gram_marks.push_back(ev.size());
         if ((rc = mark())) return rc;
@@ -541,24 +647,30 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
         if ((rc = mark())) return rc;  // end of gram == start of chol
 
         for (int j = 0; j < p.nrb; ++j) {
+            if (timing) diag_marks.push_back(ev.size());
+            if ((rc = mark())) return rc;
             hipLaunchKernelGGL(diag_kernel, dim3((unsigned)bc), dim3(THREADS), DIAG_LDS, stream, p, j);
             BARK_LAUNCH_CHECK();
+            if ((rc = mark())) return rc;
             const int n_right = p.ncb - j - 1;
             const int n_diag = (j + 1 < p.nrb) ? 1 : 0;
             if (j >= 1 && n_right + n_diag > 0) {
                 if (timing) panel_marks.push_back(ev.size());
                 if ((rc = mark())) return rc;
-                hipLaunchKernelGGL(panel_kernel, dim3((unsigned)(n_right + n_diag), (unsigned)bc), dim3(THREADS),
-                                   GEMM_LDS, stream, p, j, n_right);
+                hipLaunchKernelGGL(panel_kernel, dim3(xcd_grid(n_right + n_diag, (int)bc)), dim3(THREADS), GEMM_LDS,
+                                   stream, p, j, n_right, n_right + n_diag);
                 BARK_LAUNCH_CHECK();
                 if ((rc = mark())) return rc;
                 panel_flops += 2.0 * NB * NB * (double)(j * NB) * (double)(n_right + n_diag) * (double)bc;
-                ++panel_launches;
             }
             if (n_right > 0) {
-                hipLaunchKernelGGL(solve_kernel, dim3((unsigned)n_right, (unsigned)bc), dim3(THREADS), GEMM_LDS, stream,
-                                   p, j);
+                if (timing) solve_marks.push_back(ev.size());
+                if ((rc = mark())) return rc;
+                hipLaunchKernelGGL(solve_kernel, dim3(xcd_grid(n_right, (int)bc)), dim3(THREADS), GEMM_LDS, stream, p, j,
+                                   n_right);
                 BARK_LAUNCH_CHECK();
+                if ((rc = mark())) return rc;
+                solve_flops += 2.0 * NB * NB * (double)NB * (double)n_right * (double)bc;
             }
         }
         hipLaunchKernelGGL(finish_mll_kernel, dim3((unsigned)((bc + 255) / 256)), dim3(256), 0, stream, p.accum, (int)bc,
@@ -582,16 +694,23 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
             *acc += ms;
             return BARK_OK;
         };
-        timing->gram_ms = timing->chol_ms = timing->panel_ms = 0.f;
+        timing->gram_ms = timing->chol_ms = timing->diag_ms = timing->panel_ms = timing->solve_ms = 0.f;
         for (size_t k = 0; k < gram_marks.size(); ++k) {
             // chunk k: events [g0, g1 (== chol start), (panel pairs...), chol end]
             if ((rc = span(gram_marks[k], gram_marks[k] + 1, &timing->gram_ms))) return rc;
             if ((rc = span(gram_marks[k] + 1, chol_marks[k], &timing->chol_ms))) return rc;
         }
+        for (size_t a : diag_marks)
+            if ((rc = span(a, a + 1, &timing->diag_ms))) return rc;
         for (size_t a : panel_marks)
             if ((rc = span(a, a + 1, &timing->panel_ms))) return rc;
-        timing->n_panel_launches = panel_launches;
+        for (size_t a : solve_marks)
+            if ((rc = span(a, a + 1, &timing->solve_ms))) return rc;
+        timing->n_diag_launches = (int64_t)diag_marks.size();
+        timing->n_panel_launches = (int64_t)panel_marks.size();
+        timing->n_solve_launches = (int64_t)solve_marks.size();
         timing->panel_flops = panel_flops;
+        timing->solve_flops = solve_flops;
         for (hipEvent_t e : ev) (void)hipEventDestroy(e);
     }
     return BARK_OK;

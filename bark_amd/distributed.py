@@ -1,0 +1,45 @@
+"""Multi-GPU layout of the hot path: independent forest samples shard across ranks.
+
+Each MCMC forest sample is an independent evaluation, so the B samples are cut into
+contiguous blocks, one per rank (one process per GPU); X, y and feat_types are replicated.  There
+is no data-path collective: the only exchange is the final all-gather of the (B,) log-likelihoods
+(8 B per sample) over RCCL/xGMI (`nccl` backend) — or gloo on CPU in tests.
+"""
+
+from __future__ import annotations
+
+
+def shard_range(total: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous block [lo, hi) of `total` samples owned by `rank`; sizes differ by at most one."""
+    if not (0 <= rank < world) or total < 0:
+        raise ValueError(f"bad shard request total={total} rank={rank} world={world}")
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_mll(local, total: int, group=None):
+    """All-gather per-rank MLL blocks (sizes from shard_range) into the full (total,) vector on
+    every rank.  `local` is a 1-D float64 torch tensor on the backend's device."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized():
+        if local.shape[0] != total:
+            raise ValueError("not distributed: local block must be the whole vector")
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sizes = [shard_range(total, r, world) for r in range(world)]
+    lo, hi = sizes[rank]
+    if local.shape[0] != hi - lo:
+        raise ValueError(f"rank {rank} holds {local.shape[0]} values, expected {hi - lo}")
+    widest = max(h - l for l, h in sizes)
+    if all(h - l == widest for l, h in sizes):
+        out = torch.empty(total, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
+    padded = torch.zeros(widest, dtype=local.dtype, device=local.device)
+    padded[: hi - lo] = local
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    return torch.cat([p[: h - l] for p, (l, h) in zip(parts, sizes)])

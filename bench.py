@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py — forest-Gram + Cholesky MLL evaluations per second (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the hot path over one rank's batch of synthetic forest samples:
+leaf traversal -> N x N Gram (+ jitter) -> blocked fp64 Cholesky -> triangular solve -> log-det
+-> MLL, for every forest sample (one "eval" each), followed by the only cross-rank exchange of the
+path, the all-gather of the (B,) log-likelihoods over RCCL.  Inputs (X, y, packed forests, noise)
+are resident in HBM before the timed region; the output is the (B,) MLL vector on the device.
+
+Workload (BASELINE.json configs[2], SURVEY §8d "c3"): N=4096 points, d=8 continuous features,
+m=50 trees, B=256 forest samples PER GPU drawn from the BART depth prior (alpha .95, beta 2),
+noise_b ~ U[0.05,0.15), scale 1, MLL convention of examples/mcmc/mcmc_record_mll.py:57-74.
+Weak scaling: every rank evaluates its own 256 samples (c4's sharding, at c3's per-GPU batch).
+"""
+
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix peak (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=4096, help="training points")
+    ap.add_argument("--batch", type=int, default=256, help="forest samples per GPU")
+    ap.add_argument("--trees", type=int, default=50)
+    ap.add_argument("--dim", type=int, default=8)
+    ap.add_argument("--cpu-sample", type=int, default=3, help="forest samples timed on the host oracle (0 = skip)")
+    ap.add_argument("--chunk", type=int, default=0, help="forests factorised concurrently (0 = fit HBM)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from bark_amd import _lib, synthetic
+    from bark_amd.distributed import gather_mll
+    from bark_amd.fitting.mll import choose_chunk
+    from bark_amd.forest import PackedForest
+
+    N, B, m, d = args.n, args.batch, args.trees, args.dim
+    # ---- synthetic inputs: same X, y on every rank; rank r owns forests r*B .. r*B+B-1
+    X, y, bounds, ft = synthetic.unit_cube_problem(N, d, seed=N)
+    forests = synthetic.sample_prior_forests(B, m, bounds, ft, seed=N + rank * B)
+    noise = np.random.default_rng(N + 7919 * (rank + 1)).uniform(0.05, 0.15, size=B)
+
+    lib = _lib.lib()
+    pf = PackedForest(forests, ft)  # host format conversion + upload: outside the timed region
+    Xd = _lib.to_device(X)
+    yd = _lib.to_device(y.reshape(-1))
+    noise_d = _lib.to_device(noise)
+    mll_d = torch.empty(B, dtype=torch.float64, device=Xd.device)
+    info_d = torch.empty(B, dtype=torch.int32, device=Xd.device)
+    Bc = args.chunk or choose_chunk(B, N, 0, m)
+    ws = _lib.workspace(int(lib.bark_mll_workspace_bytes(N, 0, m, Bc)))
+    flags = _lib.MLL_INCLUDE_2PI
+    stream = _lib.stream_ptr()
+    timing = _lib.MllTiming()
+    tsum = dict(gram_ms=0.0, chol_ms=0.0, diag_ms=0.0, panel_ms=0.0, solve_ms=0.0)
+
+    def step(timed: bool):
+        _lib.check(lib.bark_mll_batched_hip(
+            _lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(yd), _lib.ptr(noise_d), None, flags,
+            None, 0, _lib.ptr(mll_d), None, None, _lib.ptr(info_d), _lib.ptr(ws), ws.numel(), Bc,
+            ctypes.byref(timing) if timed else None, stream))
+        if timed:  # HIP-event spans of this step's launches, recorded on the launch stream
+            for k in tsum:
+                tsum[k] += getattr(timing, k)
+        return gather_mll(mll_d, B * world) if world > 1 else mll_d
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        all_mll = step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=Xd.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert int(info_d.abs().max().item()) == 0, "a kernel matrix was not positive definite"
+    mll_host = all_mll.cpu().numpy()
+    assert np.isfinite(mll_host).all()
+
+    steps = args.steps
+    evals = B * world * steps
+    value = evals / elapsed
+    per_step = {k: v / steps for k, v in tsum.items()}
+    chol_flops = B * N**3 / 3.0  # algorithmic flops of one launch sequence (SURVEY §8d flops_chol x B)
+    chol_tflops = chol_flops / (per_step["chol_ms"] * 1e-3) / 1e12
+    gram_bytes = B * (8.0 * N * N + 4.0 * m * 2 * N)  # SURVEY §8d bytes_gram x B
+    result = {
+        "metric": "forest-Gram + Cholesky MLL evals/sec at N=4096, 50 trees",
+        "value": value,
+        "unit": "evals/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "c3: N=%d d=%d m=%d, %d prior forest samples per GPU (BASELINE configs[2]; "
+                        "sharding of configs[3]), noise U[0.05,0.15), mcmc_record_mll convention" % (N, d, m, B),
+            "N": N, "d": d, "trees": m, "forests_per_gpu": B, "chunk": Bc, "parallelism": "samples/%d" % world,
+        },
+        "roofline": {
+            "bound": "mfma",
+            "kernel": "Cholesky launch sequence per step (diag_kernel + panel_kernel + solve_kernel); "
+                      "panel_kernel dominates",
+            "achieved": chol_tflops,
+            "peak": F64_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": chol_tflops / F64_MFMA_PEAK_TFLOPS,
+            "traffic": None,
+            "algorithmic_flops_per_step": chol_flops,
+            "ms_per_step": {k: round(v, 3) for k, v in per_step.items()},
+            "panel_kernel": {
+                "launches_per_step": int(timing.n_panel_launches),
+                "avg_ms": per_step["panel_ms"] / max(int(timing.n_panel_launches), 1),
+                "executed_tflops": timing.panel_flops / (per_step["panel_ms"] * 1e-3) / 1e12,
+            },
+            "solve_kernel": {
+                "launches_per_step": int(timing.n_solve_launches),
+                "avg_ms": per_step["solve_ms"] / max(int(timing.n_solve_launches), 1),
+                "executed_tflops": timing.solve_flops / (per_step["solve_ms"] * 1e-3) / 1e12,
+            },
+            "diag_kernel": {
+                "launches_per_step": int(timing.n_diag_launches),
+                "avg_ms": per_step["diag_ms"] / max(int(timing.n_diag_launches), 1),
+            },
+            "gram_stage": {
+                "bound": "hbm", "algorithmic_bytes_per_step": gram_bytes,
+                "achieved_GBs": gram_bytes / (per_step["gram_ms"] * 1e-3) / 1e9, "peak_GBs": HBM_PEAK_GBS,
+                "note": "only the upper block triangle is written for the Cholesky (about half the bytes)",
+            },
+        },
+    }
+
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        # the oracle (checker) timed on this box's host cores on a bounded sample of the same workload
+        from oracle import oracle as orc
+
+        ns = min(args.cpu_sample, B)
+        t1 = time.perf_counter()
+        ref = orc.batched_mll(forests[:ns], noise[:ns], None, X, y, ft, include_scale=False, include_2pi=True)
+        cpu_s = time.perf_counter() - t1
+        t2 = time.perf_counter()
+        orc.batched_mll(forests[:ns], noise[:ns], None, X, y, ft, include_scale=False, include_2pi=True, cholesky=True)
+        chol_s = time.perf_counter() - t2
+        rel = float(np.max(np.abs(mll_host[:ns] - ref) / np.abs(ref)))
+        assert np.allclose(mll_host[:ns], ref, rtol=1e-9, atol=1e-8), (mll_host[:ns], ref)
+        result["cpu_baseline"] = {
+            "value": ns / cpu_s,
+            "unit": "evals/s",
+            "cores": os.cpu_count(),
+            "kind": "port",
+            "sample": "%d of the %d forest samples of this workload (N=%d): C leaf walk + N*N*m compare-count Gram "
+                      "(1 thread, as the reference) + numpy.linalg.inv + slogdet (LAPACK threads = cores), %.1f s"
+                      % (ns, B, N, cpu_s),
+            "cholesky_variant_evals_per_s": ns / chol_s,
+            "gpu_vs_oracle_max_rel_err": rel,
+        }
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

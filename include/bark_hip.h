@@ -124,11 +124,14 @@ int bark_gram_from_leaves_hip(const uint32_t *leaf1, int64_t N, const uint32_t *
 size_t bark_mll_workspace_bytes(int64_t N, int64_t C, int64_t m, int64_t Bc);
 
 typedef struct {
-    float gram_ms;     /* leaf traversal + Gram fill of the chunk(s) */
-    float chol_ms;     /* all factorisation launches (potrf/trsm/gemm panels + solves) */
-    float panel_ms;    /* of which: the MFMA panel-update kernel */
-    int64_t n_panel_launches;
-    double panel_flops; /* fp64 flops executed by the panel-update kernel launches */
+    float gram_ms;      /* leaf traversal + Gram fill + rhs init of the chunk(s) */
+    float chol_ms;      /* every factorisation launch: diag + panel + solve kernels, finish, predict reduce */
+    float diag_ms;      /* of which: diag_kernel  (128x128 potrf + inverse + z_j)            */
+    float panel_ms;     /* of which: panel_kernel (fp64 MFMA trailing-panel update, K = 128 j) */
+    float solve_ms;     /* of which: solve_kernel (MFMA triangular solve by the block inverse) */
+    int64_t n_diag_launches, n_panel_launches, n_solve_launches;
+    double panel_flops; /* fp64 flops executed by the panel_kernel launches */
+    double solve_flops; /* fp64 flops executed by the solve_kernel launches */
 } bark_mll_timing;
 
 int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, /* forests (device / host info) */

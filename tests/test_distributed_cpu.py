@@ -1,0 +1,73 @@
+"""world_size-2 gloo test of the multi-GPU layout (shard forests, gather MLL) on CPU.
+The per-rank evaluation is stood in by the oracle here; on the GPU box each rank runs the HIP path."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from bark_amd import synthetic
+from bark_amd.distributed import shard_range
+
+
+def test_shard_range_partitions_exactly():
+    for total in (0, 1, 7, 256, 512, 513):
+        for world in (1, 2, 3, 8):
+            blocks = [shard_range(total, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+            sizes = [h - l for l, h in blocks]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_range(512, 3, 8) == (192, 256)  # config c4: 64 samples per GPU
+    with pytest.raises(ValueError):
+        shard_range(4, 2, 2)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total, q):
+    import torch
+    import torch.distributed as dist
+
+    from bark_amd.distributed import gather_mll, shard_range as sr
+    from oracle import oracle as orc
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    X, y, bounds, ft = synthetic.mixed_problem(48, seed=3)
+    F = synthetic.sample_prior_forests(total, 20, bounds, ft, seed=30)
+    noise = np.linspace(0.05, 0.2, total)
+    lo, hi = sr(total, rank, world)
+    local = orc.batched_mll(F[lo:hi], noise[lo:hi], None, X, y, ft, include_scale=False, include_2pi=True)
+    full = gather_mll(torch.from_numpy(local), total)
+    q.put((rank, full.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [6, 5])
+def test_gather_mll_world2_gloo(total):
+    import torch.multiprocessing as mp
+
+    from oracle import oracle as orc
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    X, y, bounds, ft = synthetic.mixed_problem(48, seed=3)
+    F = synthetic.sample_prior_forests(total, 20, bounds, ft, seed=30)
+    want = orc.batched_mll(F, np.linspace(0.05, 0.2, total), None, X, y, ft, include_scale=False, include_2pi=True)
+    for rank in (0, 1):
+        assert np.array_equal(results[rank], want)
