@@ -49,6 +49,10 @@ constexpr int LDS_LD = NB + 16;  // padded row (doubles)
 constexpr int STAGE = 2 * BK * LDS_LD;  // A rows then B rows, doubles
 constexpr int GEMM_LDS_DOUBLES = 2 * STAGE;
 constexpr int THREADS = 256;
+#ifndef BARK_PANEL_DEPTH
+#define BARK_PANEL_DEPTH 1
+#endif
+constexpr int PANEL_DEPTH = BARK_PANEL_DEPTH;  // k-tiles of global-load lookahead in the panel kernel
 
 struct Lane {
     int wr, wc, lr, lk;
@@ -108,38 +112,114 @@ __device__ __forceinline__ void stage_store(const StageRegs &r, double *st, int 
     *reinterpret_cast<f64x2 *>(bs + 12 * LDS_LD) = r.b3;
 }
 
+// one k-tile (16 deep) of MFMAs from LDS stage `st`
+__device__ __forceinline__ void mma_stage(f64x4 (&acc)[4][4], const double *st, const Lane &q) {
+    const double *As = st;
+    const double *Bs = st + BK * LDS_LD;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+        const double *ar = As + (kk * 4 + q.lk) * LDS_LD + q.wr * 64 + q.lr;
+        const double *br = Bs + (kk * 4 + q.lk) * LDS_LD + q.wc * 64 + q.lr;
+        const double a0 = ar[0], a1 = ar[16], a2 = ar[32], a3 = ar[48];
+        const double b0 = br[0], b1 = br[16], b2 = br[32], b3 = br[48];
+#define BARK_MFMA(mt, nt, av, bv) acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[mt][nt], 0, 0, 0)
+        BARK_MFMA(0, 0, a0, b0); BARK_MFMA(0, 1, a0, b1); BARK_MFMA(0, 2, a0, b2); BARK_MFMA(0, 3, a0, b3);
+        BARK_MFMA(1, 0, a1, b0); BARK_MFMA(1, 1, a1, b1); BARK_MFMA(1, 2, a1, b2); BARK_MFMA(1, 3, a1, b3);
+        BARK_MFMA(2, 0, a2, b0); BARK_MFMA(2, 1, a2, b1); BARK_MFMA(2, 2, a2, b2); BARK_MFMA(2, 3, a2, b3);
+        BARK_MFMA(3, 0, a3, b0); BARK_MFMA(3, 1, a3, b1); BARK_MFMA(3, 2, a3, b2); BARK_MFMA(3, 3, a3, b3);
+#undef BARK_MFMA
+    }
+}
+
 // acc[r][c] += sum_{k<K} A[k][r] * B[k][c]   for a 128x128 tile; A, B k-major panels (row stride lda/ldb,
 // 128 contiguous doubles per row, 16-byte aligned).  K % 16 == 0.  All 256 threads; ends with a barrier.
-__device__ __forceinline__ void gemm_kmajor(f64x4 (&acc)[4][4], const double *__restrict__ A, long lda,
-                                            const double *__restrict__ B, long ldb, int K, double *lds, int tid,
-                                            const Lane &q) {
+// Pipeline: k-tile t is multiplied from LDS stage t&1 while tile t+1 sits in registers (written to the
+// other stage before the barrier) and tile t+2 is in flight from HBM/L2 into the second register set,
+// so a global load has two k-tiles (>= 8k MFMA cycles) to land.
+template <int DEPTH>
+__device__ __forceinline__ void gemm_kmajor_t(f64x4 (&acc)[4][4], const double *__restrict__ A, long lda,
+                                              const double *__restrict__ B, long ldb, int K, double *lds, int tid,
+                                              const Lane &q) {
     const int nk = K / BK;
     if (nk == 0) return;
     // thread -> (row k, column pair) of a stage: 4 passes of 256 threads x 16 B cover 16 rows x 1 KiB
     const int lrow = tid >> 6, lcol = (tid & 63) * 2;
+    if (DEPTH == 1) {
+        StageRegs regs;
+        stage_load(regs, A, lda, B, ldb, 0, lrow, lcol);
+        stage_store(regs, lds, lrow, lcol);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more = kt + 1 < nk;
+            if (more) stage_load(regs, A, lda, B, ldb, kt + 1, lrow, lcol);
+            mma_stage(acc, lds + (kt & 1) * STAGE, q);
+            if (more) stage_store(regs, lds + ((kt + 1) & 1) * STAGE, lrow, lcol);
+            __syncthreads();
+        }
+    } else {
+        StageRegs r0, r1;  // r0: odd tiles (1,3,..), r1: even tiles (2,4,..) after the prologue
+        stage_load(r0, A, lda, B, ldb, 0, lrow, lcol);
+        stage_store(r0, lds, lrow, lcol);
+        if (nk > 1) stage_load(r0, A, lda, B, ldb, 1, lrow, lcol);
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            // even half: compute tile kt (stage 0); r0 holds tile kt+1; fetch tile kt+2 into r1
+            if (kt + 2 < nk) stage_load(r1, A, lda, B, ldb, kt + 2, lrow, lcol);
+            mma_stage(acc, lds, q);
+            if (kt + 1 < nk) stage_store(r0, lds + STAGE, lrow, lcol);
+            __syncthreads();
+            if (kt + 1 >= nk) break;
+            // odd half: compute tile kt+1 (stage 1); r1 holds tile kt+2; fetch tile kt+3 into r0
+            if (kt + 3 < nk) stage_load(r0, A, lda, B, ldb, kt + 3, lrow, lcol);
+            mma_stage(acc, lds + STAGE, q);
+            if (kt + 2 < nk) stage_store(r1, lds, lrow, lcol);
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ void gemm_kmajor(f64x4 (&acc)[4][4], const double *__restrict__ A, long lda,
+                                            const double *__restrict__ B, long ldb, int K, double *lds, int tid,
+                                            const Lane &q) {
+    gemm_kmajor_t<1>(acc, A, lda, B, ldb, K, lds, tid, q);
+}
+
+// Row-tile map of the triangular solve: W is upper triangular, so output row tile rt (16 rows) only needs
+// k-tiles kt <= rt.  Wave-row 0 owns row tiles {0,3,4,7}, wave-row 1 owns {1,2,5,6}: 18 (k-tile, row-tile)
+// products each instead of 32, perfectly balanced.
+
+// acc[rt(mt)][nt] += sum_k W[k][r] T[k][c] with W (A operand, row stride 128) upper triangular: k-tiles above
+// a row tile are skipped.  Same staging/pipeline as gemm_kmajor (K = 128).
+__device__ __forceinline__ void gemm_upper_tri(f64x4 (&acc)[4][4], const int (&rt)[4], const double *__restrict__ W,
+                                               const double *__restrict__ T, long ldt, double *lds, int tid,
+                                               const Lane &q) {
+    constexpr int nk = NB / BK;
+    const int lrow = tid >> 6, lcol = (tid & 63) * 2;
     StageRegs regs;
-    stage_load(regs, A, lda, B, ldb, 0, lrow, lcol);
+    stage_load(regs, W, NB, T, ldt, 0, lrow, lcol);
     stage_store(regs, lds, lrow, lcol);
     __syncthreads();
+#pragma unroll
     for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) stage_load(regs, A, lda, B, ldb, kt + 1, lrow, lcol);
+        if (kt + 1 < nk) stage_load(regs, W, NB, T, ldt, kt + 1, lrow, lcol);
         const double *As = lds + (kt & 1) * STAGE;
         const double *Bs = As + BK * LDS_LD;
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
-            const double *ar = As + (kk * 4 + q.lk) * LDS_LD + q.wr * 64 + q.lr;
             const double *br = Bs + (kk * 4 + q.lk) * LDS_LD + q.wc * 64 + q.lr;
-            const double a0 = ar[0], a1 = ar[16], a2 = ar[32], a3 = ar[48];
             const double b0 = br[0], b1 = br[16], b2 = br[32], b3 = br[48];
-#define BARK_MFMA(mt, nt, av, bv) acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[mt][nt], 0, 0, 0)
-            BARK_MFMA(0, 0, a0, b0); BARK_MFMA(0, 1, a0, b1); BARK_MFMA(0, 2, a0, b2); BARK_MFMA(0, 3, a0, b3);
-            BARK_MFMA(1, 0, a1, b0); BARK_MFMA(1, 1, a1, b1); BARK_MFMA(1, 2, a1, b2); BARK_MFMA(1, 3, a1, b3);
-            BARK_MFMA(2, 0, a2, b0); BARK_MFMA(2, 1, a2, b1); BARK_MFMA(2, 2, a2, b2); BARK_MFMA(2, 3, a2, b3);
-            BARK_MFMA(3, 0, a3, b0); BARK_MFMA(3, 1, a3, b1); BARK_MFMA(3, 2, a3, b2); BARK_MFMA(3, 3, a3, b3);
-#undef BARK_MFMA
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                if (kt <= rt[mt]) {  // wave-uniform
+                    const double a = As[(kk * 4 + q.lk) * LDS_LD + rt[mt] * 16 + q.lr];
+                    acc[mt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc[mt][0], 0, 0, 0);
+                    acc[mt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc[mt][1], 0, 0, 0);
+                    acc[mt][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b2, acc[mt][2], 0, 0, 0);
+                    acc[mt][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b3, acc[mt][3], 0, 0, 0);
+                }
+            }
         }
-        if (more) stage_store(regs, lds + ((kt + 1) & 1) * STAGE, lrow, lcol);
+        if (kt + 1 < nk) stage_store(regs, lds + ((kt + 1) & 1) * STAGE, lrow, lcol);
         __syncthreads();
     }
 }
@@ -380,7 +460,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_kernel(Mats p, int j, int n_
     }
     f64x4 acc[4][4];
     zero_acc(acc);
-    gemm_kmajor(acc, Ab + (size_t)rb * NB, p.ld, Ab + (size_t)cb * NB, p.ld, j * NB, lds, tid, q);
+    gemm_kmajor_t<PANEL_DEPTH>(acc, Ab + (size_t)rb * NB, p.ld, Ab + (size_t)cb * NB, p.ld, j * NB, lds, tid, q);
     double *tile = Ab + (size_t)rb * NB * p.ld + (size_t)cb * NB;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -411,13 +491,16 @@ __global__ __launch_bounds__(THREADS, 2) void solve_kernel(Mats p, int j, int n_
 
     f64x4 acc[4][4];
     zero_acc(acc);
-    // D[r][c] = sum_k W[k][r] T[k][c]
-    gemm_kmajor(acc, Wb, NB, tile, p.ld, NB, lds, tid, q);
+    // D[r][c] = sum_{k<=r} W[k][r] T[k][c]; this wave's 4 row tiles (16 rows each)
+    // (readfirstlane: the skip branches around MFMAs must be scalar branches, MFMA ignores EXEC)
+    const int wr_u = __builtin_amdgcn_readfirstlane(q.wr);
+    const int rt[4] = {wr_u ? 1 : 0, wr_u ? 2 : 3, wr_u ? 5 : 4, wr_u ? 6 : 7};
+    gemm_upper_tri(acc, rt, Wb, tile, p.ld, lds, tid, q);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            double *row = tile + (size_t)acc_row(q, mt, v) * p.ld;
+            double *row = tile + (size_t)(rt[mt] * 16 + q.lk + 4 * v) * p.ld;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) row[acc_col(q, nt)] = acc[mt][nt][v];
         }
@@ -434,7 +517,7 @@ __global__ __launch_bounds__(THREADS, 2) void solve_kernel(Mats p, int j, int n_
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const double z = zs[acc_row(q, mt, v)];
+            const double z = zs[rt[mt] * 16 + q.lk + 4 * v];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) s[nt] = fma(acc[mt][nt][v], z, s[nt]);
         }
