@@ -185,10 +185,14 @@ __device__ __forceinline__ void gemm_kmajor_dma(f64x4 (&acc)[4][4], const double
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
+#if BARK_ABLATE < 3
         if (kt + 1 < nk) stage_dma(A, lda, B, ldb, kt + 1, lds + ((kt + 1) & 1) * STAGE, wave, lane);
+#endif
         mma_stage(acc, lds + (kt & 1) * STAGE, q);
+#if BARK_ABLATE < 4
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#endif
     }
 }
 

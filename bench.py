@@ -36,6 +36,26 @@ F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix peak (256 C
 HBM_PEAK_GBS = 8000.0
 
 
+def hbm_traffic_from_profile():
+    """HBM bytes per step of the Cholesky launch sequence, from the committed rocprofv3 PMC passes of this
+    same command (profiles/rNN/*hbm_counters*.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc
+    runs, KiB units, FETCH doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on gfx950).
+    bench.py cannot collect PMC counters itself; None when no profile is committed."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*hbm_counters*.json")))
+    if not files:
+        return None
+    try:
+        prof = json.load(open(files[-1]))
+        total = 0.0
+        for k in ("diag_kernel", "panel_kernel", "solve_kernel"):
+            total += 2.0 * prof["FETCH_SIZE"][k]["sum_KiB"] * 1024.0 + prof["WRITE_SIZE"][k]["sum_KiB"] * 1024.0
+        return {"bytes_per_step": total, "source": os.path.relpath(files[-1], ROOT)}
+    except Exception:
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,7 +175,7 @@ def main():
             "peak": F64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": chol_tflops / F64_MFMA_PEAK_TFLOPS,
-            "traffic": None,
+            "traffic": hbm_traffic_from_profile(),
             "algorithmic_flops_per_step": chol_flops,
             "ms_per_step": {k: round(v, 3) for k, v in per_step.items()},
             "panel_kernel": {

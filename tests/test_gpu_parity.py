@@ -200,6 +200,21 @@ def test_posterior_against_oracle_ragged(B):
     assert np.allclose(mu, mu0, rtol=1e-9, atol=1e-9) and np.allclose(var, var0, rtol=1e-9, atol=1e-9)
 
 
+def test_beyond_4096_ragged_with_candidates(B):
+    """N = 5003 (40 block rows, ragged), mixed cat/int/cont, C = 300 candidates in the same sweep;
+    reference arithmetic (LU inv) via the oracle."""
+    X, y, bounds, ft = B.syn.mixed_problem(5003, seed=55)
+    cand, _, _, _ = B.syn.mixed_problem(300, seed=56)
+    F = B.syn.sample_prior_forests(2, 50, bounds, ft, seed=55)
+    noise, scale = np.array([0.1, 0.06]), np.array([1.0, 1.2])
+    mu, var = B.tk.forest_predict((F, noise, scale), (X, y), cand, ft)
+    mu0, var0 = B.orc.forest_predict((F, noise, scale), (X, y), cand, ft)
+    assert np.allclose(mu, mu0, rtol=1e-9, atol=1e-9) and np.allclose(var, var0, rtol=1e-9, atol=1e-9)
+    got = B.fit.batched_mll(F, noise, scale, X, y, ft, include_scale=True, include_2pi=False)
+    want = B.orc.batched_mll(F, noise, scale, X, y, ft, include_scale=True, include_2pi=False)
+    assert np.allclose(got, want, rtol=MLL_RTOL, atol=MLL_ATOL), (got, want)
+
+
 def test_not_positive_definite_raises(B):
     g = load_golden("g8_batched_mll")
     forest, X, y, ft = raw(B, g["forest"]), g["X"], g["y"], g["feat_types"]
