@@ -313,6 +313,12 @@ struct Mats {
     int nrb;              // row blocks  (Npad / 128)
     int ncb;              // column blocks incl. candidate blocks
     int Bc;               // matrices in this chunk
+    // fused Gram generation (MLL-only path): tiles of A = [scale*] K + (1e-6+noise) I are produced in the
+    // panel epilogue from the byte-packed leaf ids instead of being read back from HBM
+    const uint32_t *leafx;  // (Bc, W, npad) or nullptr when A is materialised
+    const double *scale;    // (Bc,) or nullptr
+    const double *noise;    // (Bc,)
+    int nW, m, N;  // dwords of leaf ids per point, trees, real points
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -509,6 +515,7 @@ __global__ __launch_bounds__(THREADS) void diag_kernel(Mats p, int j) {
 // panel_kernel: T[j,i] = A[j,i] - sum_{k<j} U[k,j]' U[k,i]  for i > j (all column blocks), and the
 // partial diagonal tile (j+1, j+1).  1-D grid, (matrix, tile) from xcd_map.
 // ---------------------------------------------------------------------------------------------
+template <int GEN>  // 0: A tile read from HBM; 1: generated from leaf ids (ids < 128); 2: generated (ids < 256)
 __global__ __launch_bounds__(THREADS, 2) void panel_kernel(Mats p, int j, int n_right, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
@@ -526,8 +533,6 @@ __global__ __launch_bounds__(THREADS, 2) void panel_kernel(Mats p, int j, int n_
     f64x4 acc[4][4];
     zero_acc(acc);
 #if BARK_PANEL_STAGGER
-    // de-phase the two workgroups that share a CU (same loop, one barrier per k-tile): every other
-    // workgroup of an XCD's sequence starts about half a k-tile late (speed only)
     if ((blockIdx.x / NXCD) & 1) __builtin_amdgcn_s_sleep(BARK_PANEL_STAGGER);
 #endif
 #if BARK_PANEL_DMA
@@ -536,17 +541,68 @@ __global__ __launch_bounds__(THREADS, 2) void panel_kernel(Mats p, int j, int n_
     gemm_kmajor_t<PANEL_DEPTH>(acc, Ab + (size_t)rb * NB, p.ld, Ab + (size_t)cb * NB, p.ld, j * NB, lds, tid, q);
 #endif
     double *tile = Ab + (size_t)rb * NB * p.ld + (size_t)cb * NB;
+    if (GEN == 0) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                double *row = tile + (size_t)acc_row(q, mt, v) * p.ld;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int cc = acc_col(q, nt);
+                    row[cc] = row[cc] - acc[mt][nt][v];
+                }
+            }
+        return;
+    }
+    // ---- fused Gram: A[r][c] = [scale *] (1/m) * #{t: leaf ids agree}  (+ jitter on the global diagonal) ----
+    const int npad = p.nrb * NB;
+    uint32_t *rows_l = reinterpret_cast<uint32_t *>(lds);  // [W][128] ids of this tile's rows
+    uint32_t *cols_l = rows_l + p.nW * NB;                   // [W][128] ids of this tile's columns
+    const uint32_t *lb = p.leafx + (size_t)b * p.nW * npad;
+    for (int e = tid; e < p.nW * NB; e += THREADS) {
+        const int w = e >> 7, r = e & (NB - 1);
+        rows_l[e] = lb[(size_t)w * npad + rb * NB + r];
+        cols_l[e] = lb[(size_t)w * npad + cb * NB + r];
+    }
+    __syncthreads();
+    const double inv_m = 1.0 / (double)p.m;
+    const bool has_scale = p.scale != nullptr;
+    const double sc = has_scale ? p.scale[b] : 1.0;
+    const double jitter = 1e-6 + p.noise[b];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        uint32_t miss[4][4] = {};
+        for (int w = 0; w < p.nW; ++w) {
+            uint32_t cw[4], rw[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) cw[nt] = cols_l[w * NB + acc_col(q, nt)];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) rw[v] = rows_l[w * NB + acc_row(q, mt, v)];
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) miss[v][nt] += mismatched_bytes<GEN == 1>(rw[v], cw[nt]);
+        }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            double *row = tile + (size_t)acc_row(q, mt, v) * p.ld;
+            const int r = acc_row(q, mt, v), gi = rb * NB + r;
+            double *row = tile + (size_t)r * p.ld;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const int cc = acc_col(q, nt);
-                row[cc] = row[cc] - acc[mt][nt][v];
+                const int cc = acc_col(q, nt), gj = cb * NB + cc;
+                double val;
+                if (gi < p.N && gj < p.N) {
+                    val = inv_m * (double)(p.m - (int)miss[v][nt]);
+                    if (has_scale) val = sc * val;
+                    if (gi == gj) val = val + jitter;
+                } else {
+                    val = gi == gj ? 1.0 : 0.0;  // identity padding
+                }
+                row[cc] = val - acc[mt][nt][v];
             }
         }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -714,7 +770,11 @@ int set_lds_limits() {
     if (done) return BARK_OK;
     BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(diag_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)DIAG_LDS));
-    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(panel_kernel),
+    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(panel_kernel<0>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS + debug_extra_lds())));
+    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(panel_kernel<1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS + debug_extra_lds())));
+    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(panel_kernel<2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS + debug_extra_lds())));
     BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(solve_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
@@ -773,6 +833,13 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
     uint32_t *leafc = reinterpret_cast<uint32_t *>(ws + L.off_leafc);
     const bool seven = info->max_leaves <= 128;
     const bool use_scale = (flags & BARK_MLL_INCLUDE_SCALE) != 0;
+    // MLL-only sweeps generate A inside the panel kernel; only block rows 0 and 1 are materialised
+    // (inputs of diag(0), solve(0), diag(1)).  With candidates the whole matrix is filled up front.
+    static const bool fuse_env = getenv("BARK_NO_FUSED_GRAM") == nullptr;
+    const bool fused = fuse_env && C == 0 && (size_t)2 * L.W * NB * sizeof(uint32_t) <= GEMM_LDS;
+    p.nW = (int)L.W;
+    p.m = (int)m;
+    p.N = (int)N;
 
     std::vector<hipEvent_t> ev;  // timing mode only: chunk marks + one event pair per factorisation launch
     auto mark = [&]() -> int {
@@ -797,7 +864,11 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
         if (timing) gram_marks.push_back(ev.size());
         if ((rc = mark())) return rc;
         if ((rc = bark_leaf_bytes_hip(packed_c, &sub, X, N, d, leafx, stream))) return rc;
-        rc = launch_gram(leafx, (int)L.npad, leafx, (int)L.npad, bc, m, (int)N, (int)N, (int)L.npad, (int)L.npad,
+        p.leafx = fused ? leafx : nullptr;
+        p.scale = use_scale ? scale + c0 : nullptr;
+        p.noise = noise + c0;
+        const int fill_rows = fused ? (int)(L.npad < 2 * NB ? L.npad : 2 * NB) : (int)L.npad;
+        rc = launch_gram(leafx, (int)L.npad, leafx, (int)L.npad, bc, m, (int)N, (int)N, fill_rows, (int)L.npad,
                          nullptr, use_scale ? scale + c0 : nullptr, noise + c0, p.A, L.ld, p.bstride, true, true, seven, stream);
         if (rc) return rc;
         if (C > 0) {
@@ -824,8 +895,14 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
             if (j >= 1 && n_right + n_diag > 0) {
                 if (timing) panel_marks.push_back(ev.size());
                 if ((rc = mark())) return rc;
-                hipLaunchKernelGGL(panel_kernel, dim3(xcd_grid(n_right + n_diag, (int)bc)), dim3(THREADS),
-                                   GEMM_LDS + debug_extra_lds(), stream, p, j, n_right, n_right + n_diag);
+                const dim3 pg(xcd_grid(n_right + n_diag, (int)bc));
+                const size_t pl = GEMM_LDS + debug_extra_lds();
+                if (!fused)
+                    hipLaunchKernelGGL(panel_kernel<0>, pg, dim3(THREADS), pl, stream, p, j, n_right, n_right + n_diag);
+                else if (seven)
+                    hipLaunchKernelGGL(panel_kernel<1>, pg, dim3(THREADS), pl, stream, p, j, n_right, n_right + n_diag);
+                else
+                    hipLaunchKernelGGL(panel_kernel<2>, pg, dim3(THREADS), pl, stream, p, j, n_right, n_right + n_diag);
                 BARK_LAUNCH_CHECK();
                 if ((rc = mark())) return rc;
                 panel_flops += 2.0 * NB * NB * (double)(j * NB) * (double)(n_right + n_diag) * (double)bc;

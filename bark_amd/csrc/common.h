@@ -33,4 +33,18 @@ constexpr int TILE = 128;  // Cholesky block size == MFMA tile edge per workgrou
 
 inline int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
 
+// Number of differing bytes of two dwords that each pack 4 dense leaf ids (one tree per byte): a tree pair
+// agrees iff its byte of a ^ b is zero.  Ids < 128 keep bit 7 clear, so `x + 0x7f7f7f7f` cannot carry
+// between bytes (SEVEN_BIT); the general form masks first.  forest.py:87 `np.equal(x1_leaves, x2_leaves)`.
+template <bool SEVEN_BIT>
+__device__ __forceinline__ uint32_t mismatched_bytes(uint32_t a, uint32_t b) {
+    const uint32_t x = a ^ b;
+    uint32_t z;
+    if (SEVEN_BIT)
+        z = (x + 0x7f7f7f7fu) & 0x80808080u;
+    else
+        z = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
+    return __popc(z);
+}
+
 }  // namespace bark

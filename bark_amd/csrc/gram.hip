@@ -37,17 +37,6 @@ struct GramArgs {
     int upper_only;    // 1: skip 64-tiles strictly below the 128-block diagonal
 };
 
-template <bool SEVEN_BIT>
-__device__ __forceinline__ uint32_t mismatched_bytes(uint32_t a, uint32_t b) {
-    const uint32_t x = a ^ b;
-    uint32_t z;
-    if (SEVEN_BIT)
-        z = (x + 0x7f7f7f7fu) & 0x80808080u;
-    else
-        z = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
-    return __popc(z);
-}
-
 template <bool SEVEN_BIT, bool VEC2>
 __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(GramArgs p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t strips[];  // rows[W][64] | cols[W][64]
