@@ -50,19 +50,12 @@ constexpr int LDS_LD = NB + 16;  // padded row (doubles)
 constexpr int STAGE = 2 * BK * LDS_LD;  // A rows then B rows, doubles
 constexpr int GEMM_LDS_DOUBLES = 2 * STAGE;
 constexpr int THREADS = 256;
-#ifndef BARK_PANEL_DEPTH
-#define BARK_PANEL_DEPTH 1
-#endif
 #ifndef BARK_PANEL_DMA
 #define BARK_PANEL_DMA 1
 #endif
 #ifndef BARK_ABLATE
 #define BARK_ABLATE 0
 #endif
-#ifndef BARK_PANEL_STAGGER
-#define BARK_PANEL_STAGGER 0
-#endif
-constexpr int PANEL_DEPTH = BARK_PANEL_DEPTH;  // k-tiles of global-load lookahead in the panel kernel
 
 struct Lane {
     int wr, wc, lr, lk;
@@ -198,55 +191,27 @@ __device__ __forceinline__ void gemm_kmajor_dma(f64x4 (&acc)[4][4], const double
 
 // acc[r][c] += sum_{k<K} A[k][r] * B[k][c]   for a 128x128 tile; A, B k-major panels (row stride lda/ldb,
 // 128 contiguous doubles per row, 16-byte aligned).  K % 16 == 0.  All 256 threads; ends with a barrier.
-// Pipeline: k-tile t is multiplied from LDS stage t&1 while tile t+1 sits in registers (written to the
-// other stage before the barrier) and tile t+2 is in flight from HBM/L2 into the second register set,
-// so a global load has two k-tiles (>= 8k MFMA cycles) to land.
-template <int DEPTH>
-__device__ __forceinline__ void gemm_kmajor_t(f64x4 (&acc)[4][4], const double *__restrict__ A, long lda,
-                                              const double *__restrict__ B, long ldb, int K, double *lds, int tid,
-                                              const Lane &q) {
+// Register-staged double buffer: tile t+1 travels global -> VGPR while tile t is multiplied, then
+// VGPR -> LDS (ds_write_b128) before the barrier.  Used by the short K = 128 products (diag kernel); the
+// long panel products use the LDS-DMA variant above, which avoids the ds_write bursts.
+__device__ __forceinline__ void gemm_kmajor(f64x4 (&acc)[4][4], const double *__restrict__ A, long lda,
+                                            const double *__restrict__ B, long ldb, int K, double *lds, int tid,
+                                            const Lane &q) {
     const int nk = K / BK;
     if (nk == 0) return;
     // thread -> (row k, column pair) of a stage: 4 passes of 256 threads x 16 B cover 16 rows x 1 KiB
     const int lrow = tid >> 6, lcol = (tid & 63) * 2;
-    if (DEPTH == 1) {
-        StageRegs regs;
-        stage_load(regs, A, lda, B, ldb, 0, lrow, lcol);
-        stage_store(regs, lds, lrow, lcol);
+    StageRegs regs;
+    stage_load(regs, A, lda, B, ldb, 0, lrow, lcol);
+    stage_store(regs, lds, lrow, lcol);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) stage_load(regs, A, lda, B, ldb, kt + 1, lrow, lcol);
+        mma_stage(acc, lds + (kt & 1) * STAGE, q);
+        if (more) stage_store(regs, lds + ((kt + 1) & 1) * STAGE, lrow, lcol);
         __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const bool more = kt + 1 < nk;
-            if (more) stage_load(regs, A, lda, B, ldb, kt + 1, lrow, lcol);
-            mma_stage(acc, lds + (kt & 1) * STAGE, q);
-            if (more) stage_store(regs, lds + ((kt + 1) & 1) * STAGE, lrow, lcol);
-            __syncthreads();
-        }
-    } else {
-        StageRegs r0, r1;  // r0: odd tiles (1,3,..), r1: even tiles (2,4,..) after the prologue
-        stage_load(r0, A, lda, B, ldb, 0, lrow, lcol);
-        stage_store(r0, lds, lrow, lcol);
-        if (nk > 1) stage_load(r0, A, lda, B, ldb, 1, lrow, lcol);
-        __syncthreads();
-        for (int kt = 0; kt < nk; kt += 2) {
-            // even half: compute tile kt (stage 0); r0 holds tile kt+1; fetch tile kt+2 into r1
-            if (kt + 2 < nk) stage_load(r1, A, lda, B, ldb, kt + 2, lrow, lcol);
-            mma_stage(acc, lds, q);
-            if (kt + 1 < nk) stage_store(r0, lds + STAGE, lrow, lcol);
-            __syncthreads();
-            if (kt + 1 >= nk) break;
-            // odd half: compute tile kt+1 (stage 1); r1 holds tile kt+2; fetch tile kt+3 into r0
-            if (kt + 3 < nk) stage_load(r0, A, lda, B, ldb, kt + 3, lrow, lcol);
-            mma_stage(acc, lds + STAGE, q);
-            if (kt + 2 < nk) stage_store(r1, lds, lrow, lcol);
-            __syncthreads();
-        }
     }
-}
-
-__device__ __forceinline__ void gemm_kmajor(f64x4 (&acc)[4][4], const double *__restrict__ A, long lda,
-                                            const double *__restrict__ B, long ldb, int K, double *lds, int tid,
-                                            const Lane &q) {
-    gemm_kmajor_t<1>(acc, A, lda, B, ldb, K, lds, tid, q);
 }
 
 // Row-tile map of the triangular solve: W is upper triangular, so output row tile rt (16 rows) only needs
@@ -532,13 +497,10 @@ __global__ __launch_bounds__(THREADS, 2) void panel_kernel(Mats p, int j, int n_
     }
     f64x4 acc[4][4];
     zero_acc(acc);
-#if BARK_PANEL_STAGGER
-    if ((blockIdx.x / NXCD) & 1) __builtin_amdgcn_s_sleep(BARK_PANEL_STAGGER);
-#endif
 #if BARK_PANEL_DMA
     gemm_kmajor_dma(acc, Ab + (size_t)rb * NB, p.ld, Ab + (size_t)cb * NB, p.ld, j * NB, lds, tid, q);
 #else
-    gemm_kmajor_t<PANEL_DEPTH>(acc, Ab + (size_t)rb * NB, p.ld, Ab + (size_t)cb * NB, p.ld, j * NB, lds, tid, q);
+    gemm_kmajor(acc, Ab + (size_t)rb * NB, p.ld, Ab + (size_t)cb * NB, p.ld, j * NB, lds, tid, q);
 #endif
     double *tile = Ab + (size_t)rb * NB * p.ld + (size_t)cb * NB;
     if (GEN == 0) {

@@ -147,6 +147,19 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, /* fore
                          bark_mll_timing *timing, /* optional (host); when non-NULL the call synchronises */
                          void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Woodbury / determinant-lemma updates — quick_inverse.py:13-33 (the per-tree step of the sampler,
+ * bark_sampler.py:233-257).  With mul = -1 if `subtract` else +1:
+ *   K_out         = K_inv - K_inv U (mul I + U' K_inv U)^-1 U' K_inv          (low_rank_inv_update)
+ *   logabsdet_out = log|det(I + mul U' K_inv U)|                              (low_rank_det_update adds K_logdet)
+ * K_inv, K_out: (N, N) device (K_out may alias K_inv or be NULL); U: (N, r) device, r <= 64;
+ * logabsdet_out: device scalar or NULL.  `symmetric != 0` promises K_inv == K_inv' and saves one pass.
+ * ------------------------------------------------------------------------------------- */
+size_t bark_lowrank_workspace_bytes(int64_t N, int64_t r);
+int bark_lowrank_update_hip(const double *K_inv, int64_t N, const double *U, int64_t r, int subtract, int symmetric,
+                            double *K_out, double *logabsdet_out, void *workspace, size_t workspace_bytes,
+                            void *stream);
+
 /* quick_inverse.py:37-38  mll(K_inv, K_logdet, y) = 0.5 * (-y' K_inv y - K_logdet), on device. */
 int bark_quadform_hip(const double *K_inv, const double *y, int64_t N, double *out, void *stream);
 

@@ -215,6 +215,66 @@ def test_beyond_4096_ragged_with_candidates(B):
     assert np.allclose(got, want, rtol=MLL_RTOL, atol=MLL_ATOL), (got, want)
 
 
+def test_g9_woodbury_updates(B):
+    """quick_inverse.py:13-33 on device vs the reference's outputs (tests/bark_fitting/test_quick_inverse.py:13-52)."""
+    g = load_golden("g9_woodbury")
+    qi = B.fit.quick_inverse
+    for i in range(3):
+        A, U, A_inv, logdet = g[f"A{i}"], g[f"U{i}"], g[f"Ainv{i}"], float(g[f"logdet{i}"])
+        assert np.allclose(qi.low_rank_inv_update(A_inv, U), g[f"inv_add{i}"], rtol=1e-9, atol=1e-11)
+        assert np.allclose(qi.low_rank_inv_update(A_inv, U, subtract=True), g[f"inv_sub{i}"], rtol=1e-9, atol=1e-11)
+        assert np.isclose(qi.low_rank_det_update(A_inv, U, logdet), g[f"det_add{i}"], rtol=1e-11)
+        assert np.isclose(qi.low_rank_det_update(A_inv, U, logdet, subtract=True), g[f"det_sub{i}"], rtol=1e-11)
+        # the reference's own assertions
+        assert np.isclose(qi.low_rank_inv_update(A_inv, U), np.linalg.inv(A + U @ U.T)).all()
+        assert np.isclose(qi.low_rank_inv_update(A_inv, U, subtract=True), np.linalg.inv(A - U @ U.T)).all()
+
+
+def test_g2_sampler_tree_swap_chain_on_device(B):
+    """The per-tree step of the sampler (bark_sampler.py:233-257) with K_inv resident on the GPU:
+    subtract the old tree's leaf vectors, add the new tree's, compare with the exact recomputation
+    (tests/bark_fitting/test_quick_inverse.py:55-101)."""
+    torch = B.torch
+    g = load_golden("g2_two_tree_kat")
+    qi = B.fit.quick_inverse
+    forest, new_nodes, x, ft = raw(B, g["forest"]), raw(B, g["new_nodes"]), g["x"], g["feat_types"]
+    s = np.sqrt(0.5 / 2)
+    cur = s * B.bf.get_leaf_vectors(forest[0], x, ft)
+    new = s * B.bf.get_leaf_vectors(new_nodes, x, ft)
+    K_inv = torch.from_numpy(g["K_inv"]).cuda()
+    logdet = float(g["K_logdet"])
+    inv1 = qi.low_rank_inv_update(K_inv, torch.from_numpy(cur).cuda(), subtract=True)
+    det1 = qi.low_rank_det_update(K_inv, torch.from_numpy(cur).cuda(), logdet, subtract=True)
+    inv2 = qi.low_rank_inv_update(inv1, torch.from_numpy(new).cuda())
+    det2 = qi.low_rank_det_update(inv1, torch.from_numpy(new).cuda(), det1)
+    assert inv2.is_cuda
+    assert np.allclose(inv1.cpu().numpy(), g["inv_after_subtract"]) and np.isclose(float(det1), g["det_after_subtract"])
+    assert np.isclose(float(det2), g["K_swapped_logdet"]) and np.isclose(inv2.cpu().numpy(), g["K_swapped_inv"]).all()
+    y = torch.linspace(-1, 1, 20, dtype=torch.float64).reshape(-1, 1).cuda()
+    want = B.orc.mll(g["K_swapped_inv"], float(g["K_swapped_logdet"]), y.cpu().numpy())
+    assert np.isclose(float(qi.mll(inv2, det2, y)), want, rtol=1e-10)
+
+
+def test_woodbury_large_against_oracle(B):
+    """N = 1500, r = 7 / 33 / 64: one-hot style and dense U, symmetric SPD K_inv."""
+    rng = np.random.default_rng(3)
+    N = 1500
+    A = rng.standard_normal((N, N)) / np.sqrt(N)
+    K_inv = np.linalg.inv(A @ A.T + np.eye(N))
+    _, logdet = np.linalg.slogdet(A @ A.T + np.eye(N))
+    qi = B.fit.quick_inverse
+    for r in (7, 33, 64):
+        U = rng.standard_normal((N, r)) * 0.05
+        for sub in (False, True):
+            got = qi.low_rank_inv_update(K_inv, U, subtract=sub)
+            want = B.orc.low_rank_inv_update(K_inv, U, subtract=sub)
+            assert np.allclose(got, want, rtol=1e-9, atol=1e-11)
+            assert np.isclose(qi.low_rank_det_update(K_inv, U, logdet, subtract=sub),
+                              B.orc.low_rank_det_update(K_inv, U, logdet, subtract=sub), rtol=1e-12)
+    with pytest.raises(ValueError):
+        qi.low_rank_inv_update(K_inv, rng.standard_normal((N, 65)))
+
+
 def test_not_positive_definite_raises(B):
     g = load_golden("g8_batched_mll")
     forest, X, y, ft = raw(B, g["forest"]), g["X"], g["y"], g["feat_types"]

@@ -140,6 +140,8 @@ def test_reference_api_surface():
     assert np.array_equal(bf.create_empty_forest(3, 10), orc.create_empty_forest(3, 10))
     for n in ("mll", "low_rank_inv_update", "low_rank_det_update"):
         assert hasattr(fit.quick_inverse, n)
+    assert _lib.lib().bark_lowrank_workspace_bytes(4096, 8) >= 3 * 4096 * 8 * 8
+    assert _lib.lib().bark_lowrank_workspace_bytes(4096, 65) == 0
     assert hasattr(fit, "mll") and hasattr(fit, "batched_mll")
     assert hasattr(tk, "forest_predict") and hasattr(tk, "mixture_of_gaussians_as_normal")
     g = load_golden("g6_predict")
