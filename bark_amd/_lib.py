@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libbarkhip.so")
 
 BARK_OK = 0
 BARK_ERR_ARG, BARK_ERR_TREE, BARK_ERR_CATEGORICAL, BARK_ERR_HIP, BARK_ERR_WORKSPACE = 1, 2, 3, 4, 5
-MLL_INCLUDE_SCALE, MLL_INCLUDE_2PI = 1, 2
+MLL_INCLUDE_SCALE, MLL_INCLUDE_2PI, MLL_RHS_IDENTITY = 1, 2, 4
 
 i64, vp, ci = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int
 
@@ -50,8 +50,8 @@ SIGNATURES = {
     "bark_leaf_bytes_hip": (ci, [vp, ctypes.POINTER(PackInfo), vp, i64, i64, vp, vp]),
     "bark_gram_from_leaves_hip": (ci, [vp, i64, vp, i64, i64, i64, i64, vp, vp, vp, vp, i64, i64, vp]),
     "bark_mll_workspace_bytes": (ctypes.c_size_t, [i64, i64, i64, i64]),
-    "bark_mll_batched_hip": (ci, [vp, ctypes.POINTER(PackInfo), vp, i64, i64, vp, vp, vp, ci, vp, i64, vp, vp, vp, vp,
-                                  vp, ctypes.c_size_t, i64, ctypes.POINTER(MllTiming), vp]),
+    "bark_mll_batched_hip": (ci, [vp, ctypes.POINTER(PackInfo), vp, i64, i64, vp, vp, vp, vp, ci, vp, i64, vp, vp, vp,
+                                  vp, vp, vp, ctypes.c_size_t, i64, ctypes.POINTER(MllTiming), vp]),
     "bark_quadform_hip": (ci, [vp, vp, i64, vp, vp]),
     "bark_lowrank_workspace_bytes": (ctypes.c_size_t, [i64, i64]),
     "bark_lowrank_update_hip": (ci, [vp, i64, vp, i64, ci, ci, vp, vp, vp, ctypes.c_size_t, vp]),

@@ -282,6 +282,7 @@ struct Mats {
     // panel epilogue from the byte-packed leaf ids instead of being read back from HBM
     const uint32_t *leafx;  // (Bc, W, npad) or nullptr when A is materialised
     const double *scale;    // (Bc,) or nullptr
+    const double *shift;    // (Bc,) or nullptr (no-null kernel)
     const double *noise;    // (Bc,)
     int nW, m, N;  // dwords of leaf ids per point, trees, real points
 };
@@ -529,8 +530,9 @@ __global__ __launch_bounds__(THREADS, 2) void panel_kernel(Mats p, int j, int n_
     }
     __syncthreads();
     const double inv_m = 1.0 / (double)p.m;
-    const bool has_scale = p.scale != nullptr;
+    const bool has_scale = p.scale != nullptr, has_shift = p.shift != nullptr;
     const double sc = has_scale ? p.scale[b] : 1.0;
+    const double sh = has_shift ? p.shift[b] : 0.0;
     const double jitter = 1e-6 + p.noise[b];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -556,6 +558,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_kernel(Mats p, int j, int n_
                 double val;
                 if (gi < p.N && gj < p.N) {
                     val = inv_m * (double)(p.m - (int)miss[v][nt]);
+                    if (has_shift) val = val - sh;
                     if (has_scale) val = sc * val;
                     if (gi == gj) val = val + jitter;
                 } else {
@@ -626,6 +629,48 @@ __global__ __launch_bounds__(THREADS, 2) void solve_kernel(Mats p, int j, int n_
     }
 }
 
+// right-hand-side block := identity (N x N inside the padded candidate columns)
+__global__ void identity_rhs_kernel(Mats p, int N, int cpad) {
+    const int b = blockIdx.z, r = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < cpad) p.A[(size_t)b * p.bstride + (size_t)r * p.ld + (size_t)p.nrb * NB + c] = (r == c && r < N) ? 1.0 : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// vtv_kernel: out[ci][cj] = base + sign * sum_k V[k][ci] V[k][cj] over the candidate columns
+// (V = U^-T K_Xx sits in the extra block columns after the sweep).  Same k-major MFMA product as the
+// panel kernel.  `tri`: V = U^-T is lower triangular (identity right-hand side), so the sum starts at
+// block row max(ti, tj).  Full covariance: base = scale_b, sign = -1.  Inverse: base = 0, sign = +1.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS, 2) void vtv_kernel(Mats p, int nct, int C, const double *base, double sign,
+                                                          int tri, double *out) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x;
+    int b, t;
+    if (!xcd_map(blockIdx.x, nct * nct, p.Bc, b, t)) return;
+    const Lane q = lane_of(tid);
+    const int ti = t / nct, tj = t - ti * nct;
+    const int kb = tri ? (ti > tj ? ti : tj) : 0;
+    const double *Vb = p.A + (size_t)b * p.bstride + (size_t)kb * NB * p.ld + (size_t)p.nrb * NB;
+    f64x4 acc[4][4];
+    zero_acc(acc);
+    gemm_kmajor_dma(acc, Vb + (size_t)ti * NB, p.ld, Vb + (size_t)tj * NB, p.ld, (p.nrb - kb) * NB, lds, tid, q);
+    const double bs = base ? base[b] : 0.0;
+    double *ob = out + (size_t)b * C * C;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = ti * NB + acc_row(q, mt, v);
+            if (r >= C) continue;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int cc = tj * NB + acc_col(q, nt);
+                if (cc < C) ob[(size_t)r * C + cc] = bs + sign * acc[mt][nt][v];
+            }
+        }
+}
+
 // yz[b][:] = y (zero padded); accum = 0; info = 0
 __global__ void init_rhs_kernel(const double *__restrict__ y, int N, int npad, double *yz, double *accum,
                                 int32_t *info) {
@@ -662,7 +707,7 @@ __global__ void predict_reduce_kernel(Mats p, int N, int C, const double *scale,
         s2 = fma(v, v, s2);
     }
     mu[(size_t)b * C + c] = m;
-    var[(size_t)b * C + c] = scale[b] - s2;
+    if (var) var[(size_t)b * C + c] = scale ? scale[b] - s2 : s2;  // identity rhs: diag(K_s^-1) = colsumsq(U^-T)
 }
 
 // y' K_inv y  (quick_inverse.py:38), one workgroup, grid-stride rows
@@ -738,6 +783,8 @@ int set_lds_limits() {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS + debug_extra_lds())));
     BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(panel_kernel<2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS + debug_extra_lds())));
+    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(vtv_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
     BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(solve_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
     done = true;
@@ -757,8 +804,9 @@ size_t bark_mll_workspace_bytes(int64_t N, int64_t C, int64_t m, int64_t Bc) {
 }
 
 int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
-                         const double *y, const double *noise, const double *scale, int flags, const double *cand,
-                         int64_t C, double *mll_out, double *mu_out, double *var_out, int32_t *info_out,
+                         const double *y, const double *noise, const double *scale, const double *shift, int flags,
+                         const double *cand, int64_t C, double *mll_out, double *mu_out, double *var_out,
+                         double *cov_out, int32_t *info_out,
                          void *workspace, size_t workspace_bytes, int64_t Bc, bark_mll_timing *timing, void *stream_) {
     error_buffer()[0] = 0;
     if (!packed || !info || !X || !y || !noise || !mll_out || !info_out || !workspace)
@@ -767,8 +815,13 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
     if (N < 1 || d < 1 || B < 1 || C < 0 || Bc < 1 || N > (1 << 24) || C > (1 << 24))
         return fail(BARK_ERR_ARG, "bark_mll_batched_hip: bad shape N=%lld d=%lld B=%lld C=%lld Bc=%lld", (long long)N,
                     (long long)d, (long long)B, (long long)C, (long long)Bc);
-    if (C > 0 && (!cand || !mu_out || !var_out || !scale || !(flags & BARK_MLL_INCLUDE_SCALE)))
+    const bool rhs_identity = (flags & BARK_MLL_RHS_IDENTITY) != 0;
+    if (rhs_identity) {
+        if (C != N || !mu_out) return fail(BARK_ERR_ARG, "BARK_MLL_RHS_IDENTITY needs C == N and mu_out");
+    } else if (C > 0 && (!cand || !mu_out || !var_out || !scale || !(flags & BARK_MLL_INCLUDE_SCALE))) {
         return fail(BARK_ERR_ARG, "posterior predictive needs cand, mu_out, var_out, scale and BARK_MLL_INCLUDE_SCALE");
+    }
+    if (cov_out && C == 0) return fail(BARK_ERR_ARG, "cov_out without candidates");
     if ((flags & BARK_MLL_INCLUDE_SCALE) && !scale) return fail(BARK_ERR_ARG, "BARK_MLL_INCLUDE_SCALE without scale");
     if (info->max_leaves > 256) return fail(BARK_ERR_ARG, "more than 256 leaves per tree is not supported");
     if (Bc > B) Bc = B;
@@ -828,15 +881,20 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
         if ((rc = bark_leaf_bytes_hip(packed_c, &sub, X, N, d, leafx, stream))) return rc;
         p.leafx = fused ? leafx : nullptr;
         p.scale = use_scale ? scale + c0 : nullptr;
+        p.shift = shift ? shift + c0 : nullptr;
         p.noise = noise + c0;
         const int fill_rows = fused ? (int)(L.npad < 2 * NB ? L.npad : 2 * NB) : (int)L.npad;
         rc = launch_gram(leafx, (int)L.npad, leafx, (int)L.npad, bc, m, (int)N, (int)N, fill_rows, (int)L.npad,
-                         nullptr, use_scale ? scale + c0 : nullptr, noise + c0, p.A, L.ld, p.bstride, true, true, seven, stream);
+                         p.shift, use_scale ? scale + c0 : nullptr, noise + c0, p.A, L.ld, p.bstride, true, true, seven, stream);
         if (rc) return rc;
-        if (C > 0) {
+        if (rhs_identity) {
+            dim3 g((unsigned)((L.cpad + 255) / 256), (unsigned)L.npad, (unsigned)bc);
+            hipLaunchKernelGGL(identity_rhs_kernel, g, dim3(256), 0, stream, p, (int)N, (int)L.cpad);
+            BARK_LAUNCH_CHECK();
+        } else if (C > 0) {
             if ((rc = bark_leaf_bytes_hip(packed_c, &sub, cand, C, d, leafc, stream))) return rc;
             rc = launch_gram(leafx, (int)L.npad, leafc, (int)L.cpad, bc, m, (int)N, (int)C, (int)L.npad, (int)L.cpad,
-                             nullptr, scale + c0, nullptr, p.A + L.npad, L.ld, p.bstride, false, false, seven, stream);
+                             p.shift, scale + c0, nullptr, p.A + L.npad, L.ld, p.bstride, false, false, seven, stream);
             if (rc) return rc;
         }
         {
@@ -884,9 +942,17 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
         BARK_LAUNCH_CHECK();
         if (C > 0) {
             dim3 g((unsigned)((C + 255) / 256), (unsigned)bc);
-            hipLaunchKernelGGL(predict_reduce_kernel, g, dim3(256), 0, stream, p, (int)N, (int)C, scale + c0,
-                               mu_out + (size_t)c0 * C, var_out + (size_t)c0 * C);
+            hipLaunchKernelGGL(predict_reduce_kernel, g, dim3(256), 0, stream, p, (int)N, (int)C,
+                               rhs_identity ? nullptr : scale + c0, mu_out + (size_t)c0 * C,
+                               var_out ? var_out + (size_t)c0 * C : nullptr);
             BARK_LAUNCH_CHECK();
+            if (cov_out) {
+                const int nct = (int)(L.cpad / NB);
+                hipLaunchKernelGGL(vtv_kernel, dim3(xcd_grid(nct * nct, (int)bc)), dim3(THREADS), GEMM_LDS, stream, p, nct,
+                                   (int)C, rhs_identity ? nullptr : scale + c0, rhs_identity ? 1.0 : -1.0,
+                                   rhs_identity ? 1 : 0, cov_out + (size_t)c0 * C * C);
+                BARK_LAUNCH_CHECK();
+            }
         }
         if (timing) chol_marks.push_back(ev.size());
         if ((rc = mark())) return rc;

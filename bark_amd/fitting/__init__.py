@@ -1,2 +1,2 @@
-from .mll import batched_mll, mll  # noqa: F401
+from .mll import batched_kernel_inverse, batched_mll, mll  # noqa: F401
 from . import quick_inverse  # noqa: F401

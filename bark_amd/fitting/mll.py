@@ -57,7 +57,8 @@ def choose_chunk(B: int, N: int, C: int, m: int, budget_bytes: int | None = None
     return int(max(1, min(B, bc)))
 
 
-def _run(forest, noise, scale, X, y, feat_types, flags, cand=None, timing=None, chunk=None):
+def _run(forest, noise, scale, X, y, feat_types, flags, cand=None, timing=None, chunk=None, shift=None,
+         want_cov=False):
     import torch
 
     lib = _lib.lib()
@@ -80,18 +81,30 @@ def _run(forest, noise, scale, X, y, feat_types, flags, cand=None, timing=None, 
         scale_d = _lib.to_device(np.ascontiguousarray(np.asarray(scale, dtype=np.float64).reshape(-1)))
         if scale_d.shape[0] != B:
             raise ValueError(f"scale has {scale_d.shape[0]} entries for {B} forests")
+    shift_d = None
+    if shift is not None:
+        shift_d = _lib.to_device(np.ascontiguousarray(np.asarray(shift, dtype=np.float64).reshape(-1)))
+        if shift_d.shape[0] != B:
+            raise ValueError(f"shift has {shift_d.shape[0]} entries for {B} forests")
     C = 0
-    cand_d = mu = var = None
-    if cand is not None:
+    cand_d = mu = var = cov = None
+    if flags & _lib.MLL_RHS_IDENTITY:
+        C = N
+    elif cand is not None:
         cand_d, _ = _points(cand, ft.shape[0])
         _check_categorical(cand_d, ft)
         C = cand_d.shape[0]
+    if C:
         mu = torch.empty((B, C), dtype=torch.float64, device=Xd.device)
         var = torch.empty((B, C), dtype=torch.float64, device=Xd.device)
+        if want_cov:
+            cov = torch.empty((B, C, C), dtype=torch.float64, device=Xd.device)
     pf = PackedForest(nodes3, ft)
     if pf.info.max_leaves > 256:
         raise ValueError(f"trees with more than 256 leaves ({pf.info.max_leaves}) are not supported")
+    held = 0 if cov is None else cov.numel() * 8
     Bc = chunk or choose_chunk(B, N, C, pf.m)
+    del held
     nbytes = int(lib.bark_mll_workspace_bytes(N, C, pf.m, Bc))
     ws = _lib.workspace(nbytes)
     out = torch.empty(B, dtype=torch.float64, device=Xd.device)
@@ -99,14 +112,49 @@ def _run(forest, noise, scale, X, y, feat_types, flags, cand=None, timing=None, 
     tref = ctypes.byref(timing) if timing is not None else None
     _lib.check(lib.bark_mll_batched_hip(
         _lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(yd), _lib.ptr(noise_d), _lib.ptr(scale_d),
-        flags, _lib.ptr(cand_d), C, _lib.ptr(out), _lib.ptr(mu), _lib.ptr(var), _lib.ptr(info),
+        _lib.ptr(shift_d), flags, _lib.ptr(cand_d), C, _lib.ptr(out), _lib.ptr(mu), _lib.ptr(var), _lib.ptr(cov),
+        _lib.ptr(info),
         _lib.ptr(ws), ws.numel(), Bc, tref, _lib.stream_ptr()))
     bad = info.cpu().numpy()
     if bad.any():
         b = int(np.flatnonzero(bad)[0])
         raise np.linalg.LinAlgError(
             f"kernel matrix of forest sample {b} is not positive definite (pivot {int(bad[b])} <= 0)")
-    return out, mu, var
+    return (out, mu, var, cov) if want_cov else (out, mu, var)
+
+
+def batched_kernel_inverse(forest, noise, scale, X, y, feat_types, *, no_null: bool = True, return_device=False,
+                           chunk: int | None = None):
+    """Explicit inverse of the GP kernel matrix of each forest sample, as the acquisition builder needs it
+    (src/bark/optimizer/opt_model.py:54-59,101):
+
+        K_s   = scale_b * batched_forest_gram_matrix[_no_null](forest)[b] + (1e-6 + noise_b) I
+        K_inv = inv(K_s)            (B, N, N)
+        K_inv_y = K_inv @ y         (B, N)
+        logdet  = log|K_s|          (B,)
+
+    Computed from the Cholesky factor (K_inv = U^-1 U^-T: the same sweep with an identity right-hand
+    side, then one MFMA V'V product) instead of the reference's LU `np.linalg.inv`."""
+    nodes = _as_nodes(forest, 2)
+    nodes3 = nodes.reshape(-1, *nodes.shape[-2:])
+    scale = np.asarray(scale, dtype=np.float64).reshape(-1)
+    shift = None
+    if no_null:  # forest.py:102-111 folded into (shift, scale)
+        num_trees = nodes3.shape[-2]
+        num_null = np.sum(nodes3[:, :, 0]["is_leaf"], axis=-1).astype(np.int64)
+        shift = num_null / num_trees
+        scale = scale * (num_trees / np.maximum(num_trees - num_null, 1))
+    flags = _lib.MLL_INCLUDE_SCALE | _lib.MLL_RHS_IDENTITY
+    mll_noconst, K_inv_y, _, K_inv = _run(nodes3, noise, scale, X, y, feat_types, flags, chunk=chunk, shift=shift,
+                                          want_cov=True)
+    # mll = 0.5(-y'K^-1 y - logdet)  =>  logdet = -2 mll - y'K^-1 y
+    import torch
+
+    yd = _lib.to_device(y.detach() if _is_torch(y) else np.asarray(y, dtype=np.float64)).to(torch.float64).reshape(-1)
+    logdet = -2.0 * mll_noconst - K_inv_y @ yd
+    if return_device or _is_torch(X):
+        return K_inv, K_inv_y, logdet
+    return K_inv.cpu().numpy(), K_inv_y.cpu().numpy(), logdet.cpu().numpy()
 
 
 def batched_mll(forest, noise, scale, X, y, feat_types, *, include_scale: bool, include_2pi: bool,

@@ -4,7 +4,7 @@
 `forest_predict` runs one fused device sweep per chunk of forest samples: Gram(X,X), Gram(X,cand),
 blocked Cholesky with the candidate block appended as extra columns (V = U^-T K_Xx), then
 mu = V'z and var = scale - colsumsq(V).  The reference's `diag=False` full (B, C, C) covariance is
-formed only on request (it needs V'V), from the same V.  The gpytorch `LeafGP`/`LeafMOGP` classes of
+formed only on request (scale - V'V, one more MFMA product), from the same V.  The gpytorch `LeafGP`/`LeafMOGP` classes of
 the reference are out of scope.
 """
 
@@ -18,18 +18,18 @@ from ..forest import _is_torch
 
 
 def forest_predict(model, data, candidates, domain, diag: bool = True):
-    """tree_gps.py:80-113 -> (mu (B, C), var (B, C)); `domain` may be the feat_types array."""
-    if not diag:
-        raise NotImplementedError(
-            "diag=False (full B x C x C covariance, tree_gps.py:108) is not built: every caller of the "
-            "reference uses the diagonal (surrogates/bark.py:76)")
+    """tree_gps.py:80-113 -> (mu (B, C), var (B, C) or (B, C, C) if not diag); `domain` may be feat_types."""
     forest, noise, scale = model
     train_x, train_y = data
     forest = np.asarray(forest)
     noise = np.asarray(noise, dtype=np.float64).reshape(-1)   # tree_gps.py:88-90 flatten
     scale = np.asarray(scale, dtype=np.float64).reshape(-1)
     flags = _lib.MLL_INCLUDE_SCALE
-    _, mu, var = _run(forest, noise, scale, train_x, train_y, _feat_types_of(domain), flags, cand=candidates)
+    if diag:
+        _, mu, var = _run(forest, noise, scale, train_x, train_y, _feat_types_of(domain), flags, cand=candidates)
+    else:  # tree_gps.py:108: full (B, C, C) covariance scale - K_xX K^-1 K_Xx (one extra MFMA V'V product)
+        _, mu, _, var = _run(forest, noise, scale, train_x, train_y, _feat_types_of(domain), flags, cand=candidates,
+                             want_cov=True)
     if _is_torch(candidates):
         return mu, var
     return mu.cpu().numpy(), var.cpu().numpy()

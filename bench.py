@@ -111,8 +111,8 @@ def main():
 
     def step(timed: bool):
         _lib.check(lib.bark_mll_batched_hip(
-            _lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(yd), _lib.ptr(noise_d), None, flags,
-            None, 0, _lib.ptr(mll_d), None, None, _lib.ptr(info_d), _lib.ptr(ws), ws.numel(), Bc,
+            _lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(yd), _lib.ptr(noise_d), None, None, flags,
+            None, 0, _lib.ptr(mll_d), None, None, None, _lib.ptr(info_d), _lib.ptr(ws), ws.numel(), Bc,
             ctypes.byref(timing) if timed else None, stream))
         if timed:  # HIP-event spans of this step's launches, recorded on the launch stream
             for k in tsum:

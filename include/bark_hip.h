@@ -41,7 +41,9 @@ enum {
 /* MLL conventions (bit flags) */
 enum {
     BARK_MLL_INCLUDE_SCALE = 1, /* K_s = scale*K + (1e-6+noise) I   (bark_sampler.py:153-156) */
-    BARK_MLL_INCLUDE_2PI = 2    /* subtract n*log(2*pi)             (examples/mcmc/mcmc_record_mll.py:73) */
+    BARK_MLL_INCLUDE_2PI = 2,   /* subtract n*log(2*pi)             (examples/mcmc/mcmc_record_mll.py:73) */
+    BARK_MLL_RHS_IDENTITY = 4   /* right-hand-side block = I (C must equal N, cand ignored): cov_out receives
+                                   K_s^-1 and mu_out receives K_s^-1 y  (bark/optimizer/opt_model.py:54-59,101) */
 };
 
 int bark_version(void);
@@ -117,6 +119,12 @@ int bark_gram_from_leaves_hip(const uint32_t *leaf1, int64_t N, const uint32_t *
  * and get mu (B, C) and var (B, C) = scale_b - diag(K_xX K_s^-1 K_Xx)   (scale always applied,
  * as forest_predict does).
  *
+ * Full covariance (tree_gps.py:108 with diag=False): pass cov_out (B, C, C) to also get
+ *   cov_b = scale_b - K_xX K_s^-1 K_Xx     (every entry, as numpy broadcasting does).
+ * With BARK_MLL_RHS_IDENTITY the right-hand-side block is the identity instead of K_Xx: cov_out = K_s^-1
+ * (no `scale -`), mu_out = K_s^-1 y, var_out = diag(K_s^-1) — the explicit inverse the acquisition builder
+ * consumes.  `shift` (B,) or NULL subtracts n_null/m before scaling (forest.py:102-111 no-null kernel).
+ *
  * workspace: device buffer of at least bark_mll_workspace_bytes(N, C, m, Bc) bytes, where Bc
  * (1 <= Bc <= B) is the number of forests factorised concurrently; B is processed in chunks of Bc.
  * info_out (device, B int32): 0, or 1-based index of the first non-positive pivot (not PD).
@@ -138,10 +146,12 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, /* fore
                          const double *X, int64_t N, int64_t d,         /* training inputs (device) */
                          const double *y,                               /* (N,) targets (device) */
                          const double *noise, const double *scale,      /* (B,) device; scale may be NULL */
+                         const double *shift,                           /* (B,) device or NULL */
                          int flags,                                     /* BARK_MLL_* */
                          const double *cand, int64_t C,                 /* (C, d) candidates or NULL/0 */
                          double *mll_out,                               /* (B,) device */
                          double *mu_out, double *var_out,               /* (B, C) device or NULL */
+                         double *cov_out,                               /* (B, C, C) device or NULL */
                          int32_t *info_out,                             /* (B,) device */
                          void *workspace, size_t workspace_bytes, int64_t Bc,
                          bark_mll_timing *timing, /* optional (host); when non-NULL the call synchronises */

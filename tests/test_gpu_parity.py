@@ -116,6 +116,9 @@ def test_g6_forest_predict(B):
     assert mu.shape == g["mu"].shape and var.shape == g["var"].shape
     assert np.allclose(mu, g["mu"], rtol=1e-9, atol=1e-9)
     assert np.allclose(var, g["var"], rtol=1e-9, atol=1e-9)
+    mu2, full = B.tk.forest_predict(model, (g["X"], g["y"]), g["cand"], g["feat_types"], diag=False)
+    assert full.shape == g["var_full"].shape and np.array_equal(mu2, mu)
+    assert np.allclose(full, g["var_full"], rtol=1e-9, atol=1e-9)
     K_xX = B.bf.batched_forest_gram_matrix(forest.reshape(-1, *forest.shape[-2:]), g["cand"], g["X"], g["feat_types"])
     assert np.array_equal(K_xX, g["K_xX"])
     mix_mu, mix_var = B.tk.mixture_of_gaussians_as_normal(mu, var)
@@ -213,6 +216,22 @@ def test_beyond_4096_ragged_with_candidates(B):
     got = B.fit.batched_mll(F, noise, scale, X, y, ft, include_scale=True, include_2pi=False)
     want = B.orc.batched_mll(F, noise, scale, X, y, ft, include_scale=True, include_2pi=False)
     assert np.allclose(got, want, rtol=MLL_RTOL, atol=MLL_ATOL), (got, want)
+
+
+def test_kernel_inverse_for_acquisition_builder(B):
+    """opt_model.py:54-59,101: inv(scale * K_no_null + (1e-6+noise) I) and scale-free K_inv @ y, ragged N."""
+    g = load_golden("g3_prior_mixed_n257")
+    forest, X, y, ft = raw(B, g["forest"]), g["X"], g["y"], g["feat_types"]
+    noise, scale = g["noise"], g["scale"]
+    for no_null, Kref in ((True, g["K_no_null"]), (False, g["K"])):
+        K_s = scale[:, None, None] * Kref + (1e-6 + noise[:, None, None]) * np.eye(257)
+        want = np.linalg.inv(K_s)
+        K_inv, K_inv_y, logdet = B.fit.batched_kernel_inverse(forest, noise, scale, X, y, ft, no_null=no_null)
+        assert K_inv.shape == (3, 257, 257)
+        assert np.allclose(K_inv, want, rtol=1e-8, atol=1e-9)
+        assert np.allclose(K_inv_y, (want @ y)[..., 0], rtol=1e-8, atol=1e-9)
+        assert np.allclose(logdet, np.linalg.slogdet(K_s)[1], rtol=1e-10)
+        assert np.allclose(K_inv @ K_s, np.eye(257)[None], atol=1e-8)
 
 
 def test_g9_woodbury_updates(B):
