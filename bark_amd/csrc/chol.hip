@@ -300,10 +300,19 @@ struct Mats {
 //                        X[rb,jb] = -(sum_{rb<=k<jb} X[rb,k] U[k,jb]) W_jj
 // 3 barriers per kb + 2 per jb instead of ~5 per scalar column.
 // ---------------------------------------------------------------------------------------------
-constexpr int SD = NB + 8;      // row stride of S (doubles): 16-byte aligned rows, 2-way worst-case banks
 constexpr int SB = 16;          // sub-block edge
 constexpr int NSB = NB / SB;    // 8 sub-blocks per edge
 constexpr int TS = SB + 1;      // row stride of the per-wave 16x16 transpose scratch
+constexpr int NBLK = NSB * (NSB + 1) / 2;  // 36 stored sub-blocks (upper block triangle)
+
+// S is stored as a packed upper block triangle: sub-block (rb, cb), rb <= cb, is a contiguous
+// row-major 16x16 (2 KiB), so the whole 128x128 factor image takes 72 KiB instead of 136 KiB and the
+// kernel can share a CU with a panel workgroup (it runs beside panel_kernel on a helper stream).
+// A k-major MFMA operand read (4 rows x 16 columns) is one contiguous 512-B span: conflict-free.
+__device__ __forceinline__ int blk_off(int rb, int cb) { return (rb * NSB - (rb * (rb - 1)) / 2 + (cb - rb)) * SB * SB; }
+__device__ __forceinline__ double &s_at(double *S, int r, int c) {  // element (r, c), r/16 <= c/16
+    return S[blk_off(r >> 4, c >> 4) + (r & 15) * SB + (c & 15)];
+}
 
 // acc(16x16) += X' Y for two sub-blocks stored "k-major" (X[k][i], Y[k][j]) with row strides ldx, ldy
 __device__ __forceinline__ void mfma_tn(f64x4 &acc, const double *X, int ldx, const double *Y, int ldy, int lr, int lk) {
@@ -318,15 +327,15 @@ __device__ __forceinline__ void mfma_nn(f64x4 &acc, const double *X, int ldx, co
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[lr * ldx + kk * 4 + lk], Y[(kk * 4 + lk) * ldy + lr], acc, 0, 0, 0);
 }
 
-// (A): one wave eliminates the 16x16 diagonal sub-block `blk` (row stride SD) of S in registers and
-// overwrites it with W = U_kk^-1 (upper triangular, row-major).  Lane (g = l>>4, c = l&15) owns
-// rows g, g+4, g+8, g+12 of column c of [D | I].  Returns sum log(pivot) and the first bad pivot.
+// (A): one wave eliminates the 16x16 diagonal sub-block `blk` (row stride SB) in registers and overwrites
+// it with W = U_kk^-1 (upper triangular, row-major).  Lane (g = l>>4, c = l&15) owns rows g, g+4, g+8,
+// g+12 of column c of [D | I].  Returns sum log(pivot) and the first bad pivot.
 __device__ __forceinline__ void factor16(double *blk, int lane, int base_index, double &logsum, int &bad) {
     const int c = lane & 15, g = lane >> 4;
     double e[4], f[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        e[v] = blk[(g + 4 * v) * SD + c];
+        e[v] = blk[(g + 4 * v) * SB + c];
         f[v] = (g + 4 * v == c) ? 1.0 : 0.0;
     }
 #pragma unroll
@@ -357,11 +366,11 @@ __device__ __forceinline__ void factor16(double *blk, int lane, int base_index, 
         const int r = g + 4 * v;
         double dr = __shfl(e[v], g * 16 + r);  // frozen pivot of row r: lane (g, c == r), same register
         if (!(dr > 0.0)) dr = 1.0;
-        blk[c * SD + r] = f[v] / sqrt(dr);
+        blk[c * SB + r] = f[v] / sqrt(dr);
     }
 }
 
-__global__ __launch_bounds__(THREADS) void diag_kernel(Mats p, int j) {
+__global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, b = blockIdx.x;
     const Lane q = lane_of(tid);
@@ -375,19 +384,24 @@ __global__ __launch_bounds__(THREADS) void diag_kernel(Mats p, int j) {
         const double *prev = Ab + (size_t)(j - 1) * NB * p.ld + (size_t)j * NB;  // U[j-1, j]
         gemm_kmajor(acc, prev, p.ld, prev, p.ld, NB, lds, tid, q);
     }
-    double *S = lds;                              // [128][SD]
-    double *scratch = lds + NB * SD + wave * SB * TS;  // per-wave [16][TS]
-    double *vec = lds + NB * SD + 4 * SB * TS;    // [128] y / partial sums
-    double *red = vec + NB;                       // [8]
+    double *S = lds;                                          // packed upper block triangle, NBLK x [16][16]
+    double *scratch = lds + NBLK * SB * SB + wave * SB * TS;  // per-wave [16][TS]
+    double *vec = lds + NBLK * SB * SB + 4 * SB * TS;         // [128] y / partial sums
+    double *red = vec + NB;                                   // [8]
+    // D = P - U[j-1,j]'U[j-1,j]: only sub-blocks on or above the block diagonal are kept
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < 4; ++nt) {
+            const int rbk = (q.wr * 64 + mt * 16) >> 4, cbk = (q.wc * 64 + nt * 16) >> 4;  // wave-uniform
+            if (rbk <= cbk) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int r = acc_row(q, mt, v), c = acc_col(q, nt);
-                S[r * SD + c] = tile[(size_t)r * p.ld + c] - acc[mt][nt][v];
+                for (int v = 0; v < 4; ++v) {
+                    const int r = acc_row(q, mt, v), c = acc_col(q, nt);
+                    s_at(S, r, c) = tile[(size_t)r * p.ld + c] - acc[mt][nt][v];
+                }
             }
+        }
     __syncthreads();
 
     // --- blocked Cholesky D = U'U; diagonal sub-blocks end up holding W_kk = U_kk^-1 -------------
@@ -395,25 +409,26 @@ __global__ __launch_bounds__(THREADS) void diag_kernel(Mats p, int j) {
     int bad = 0;
     const int lr = q.lr, lk = q.lk;
     for (int kb = 0; kb < NSB; ++kb) {
-        double *rowk = S + kb * SB * SD;  // sub-block row kb
-        if (wave == 0) factor16(rowk + kb * SB, lane, kb * SB, logsum, bad);
+        double *dblk = S + blk_off(kb, kb);
+        if (wave == 0) factor16(dblk, lane, kb * SB, logsum, bad);
         __syncthreads();
-        for (int cb = kb + 1 + wave; cb < NSB; cb += 4) {  // (B)
+        for (int cb = kb + 1 + wave; cb < NSB; cb += 4) {  // (B) U[kb,cb] = W_kk' D[kb,cb]
+            double *blk = S + blk_off(kb, cb);
             f64x4 u = {0.0, 0.0, 0.0, 0.0};
-            mfma_tn(u, rowk + kb * SB, SD, rowk + cb * SB, SD, lr, lk);
+            mfma_tn(u, dblk, SB, blk, SB, lr, lk);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) rowk[(lk + 4 * v) * SD + cb * SB + lr] = u[v];
+            for (int v = 0; v < 4; ++v) blk[(lk + 4 * v) * SB + lr] = u[v];
         }
         __syncthreads();
         int pair = 0;
-        for (int rb = kb + 1; rb < NSB; ++rb)  // (C)
+        for (int rb = kb + 1; rb < NSB; ++rb)  // (C) D[rb,cb] -= U[kb,rb]' U[kb,cb]
             for (int cb = rb; cb < NSB; ++cb, ++pair) {
                 if ((pair & 3) != wave) continue;
                 f64x4 u = {0.0, 0.0, 0.0, 0.0};
-                mfma_tn(u, rowk + rb * SB, SD, rowk + cb * SB, SD, lr, lk);
-                double *dst = S + rb * SB * SD + cb * SB;
+                mfma_tn(u, S + blk_off(kb, rb), SB, S + blk_off(kb, cb), SB, lr, lk);
+                double *dst = S + blk_off(rb, cb);
 #pragma unroll
-                for (int v = 0; v < 4; ++v) dst[(lk + 4 * v) * SD + lr] -= u[v];
+                for (int v = 0; v < 4; ++v) dst[(lk + 4 * v) * SB + lr] -= u[v];
             }
         __syncthreads();
     }
@@ -425,8 +440,7 @@ __global__ __launch_bounds__(THREADS) void diag_kernel(Mats p, int j) {
         for (int s = 0; s < 2; ++s) {
             const int rb = wave + 4 * s;
             if (rb < jb)
-                for (int k = rb; k < jb; ++k)
-                    mfma_nn(t[s], S + rb * SB * SD + k * SB, SD, S + k * SB * SD + jb * SB, SD, lr, lk);
+                for (int k = rb; k < jb; ++k) mfma_nn(t[s], S + blk_off(rb, k), SB, S + blk_off(k, jb), SB, lr, lk);
         }
         __syncthreads();  // every product that reads U[:, jb] is done before the column is overwritten
 #pragma unroll
@@ -438,10 +452,10 @@ __global__ __launch_bounds__(THREADS) void diag_kernel(Mats p, int j) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 f64x4 x = {0.0, 0.0, 0.0, 0.0};
-                mfma_nn(x, scratch, TS, S + jb * SB * SD + jb * SB, SD, lr, lk);
-                double *dst = S + rb * SB * SD + jb * SB;
+                mfma_nn(x, scratch, TS, S + blk_off(jb, jb), SB, lr, lk);
+                double *dst = S + blk_off(rb, jb);
 #pragma unroll
-                for (int v = 0; v < 4; ++v) dst[(lk + 4 * v) * SD + lr] = -x[v];
+                for (int v = 0; v < 4; ++v) dst[(lk + 4 * v) * SB + lr] = -x[v];
                 __builtin_amdgcn_wave_barrier();
             }
         }
@@ -452,7 +466,7 @@ __global__ __launch_bounds__(THREADS) void diag_kernel(Mats p, int j) {
     double *Wb = p.W + (size_t)b * NB * NB;
     for (int e = tid; e < NB * NB; e += THREADS) {
         const int r = e >> 7, cc = e & (NB - 1);
-        Wb[e] = (r <= cc) ? S[r * SD + cc] : 0.0;
+        Wb[e] = (r <= cc) ? s_at(S, r, cc) : 0.0;
     }
 
     // --- z_j = W_j' y_j ; quad += |z_j|^2 ; logdet += 2 sum log u_kk ----------------------------
@@ -462,7 +476,7 @@ __global__ __launch_bounds__(THREADS) void diag_kernel(Mats p, int j) {
     double zz = 0.0;
     if (tid < NB) {
         double z = 0.0;
-        for (int r = 0; r <= tid; ++r) z = fma(S[r * SD + tid], vec[r], z);
+        for (int r = 0; r <= tid; ++r) z = fma(s_at(S, r, tid), vec[r], z);
         yb[tid] = z;
         zz = z * z;
     }
@@ -758,7 +772,7 @@ Layout make_layout(int64_t N, int64_t C, int64_t m, int64_t Bc) {
     return L;
 }
 
-constexpr size_t DIAG_LDS = (size_t)(NB * SD + 4 * SB * TS + NB + 8) * sizeof(double);
+constexpr size_t DIAG_LDS = (size_t)(NBLK * SB * SB + 4 * SB * TS + NB + 8) * sizeof(double);
 constexpr size_t GEMM_LDS = (size_t)GEMM_LDS_DOUBLES * sizeof(double);
 static_assert(DIAG_LDS >= GEMM_LDS, "diag kernel reuses its LDS for the K=128 GEMM stage");
 
@@ -770,6 +784,36 @@ size_t debug_extra_lds() {
         v = e ? atol(e) : 0;
     }
     return (size_t)v;
+}
+
+// diag(j) and panel(j) both depend only on solve(j-1), so they run concurrently: diag stays on the
+// caller's stream (it is dispatched the moment solve(j-1) retires and claims one slot per CU; its 82 KiB
+// of LDS leave room for a panel workgroup beside it) and the panel kernel is forked onto a helper stream
+// and joined before solve(j) (events; capturable).  Latency-bound diag waves thus share CUs with
+// MFMA-bound panel waves instead of holding the whole chip for ~0.1 ms per block column.
+struct Overlap {
+    hipStream_t helper = nullptr;
+    std::vector<hipEvent_t> events;
+};
+
+int get_overlap(Overlap **out, size_t n_events) {
+    static thread_local Overlap per_device[32];
+    int dev = 0;
+    BARK_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 32) return fail(BARK_ERR_ARG, "device index %d out of range", dev);
+    Overlap &o = per_device[dev];
+    if (!o.helper) {
+        int lo = 0, hi = 0;
+        BARK_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        BARK_HIP_CHECK(hipStreamCreateWithPriority(&o.helper, hipStreamNonBlocking, lo));
+    }
+    while (o.events.size() < n_events) {
+        hipEvent_t e;
+        BARK_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        o.events.push_back(e);
+    }
+    *out = &o;
+    return BARK_OK;
 }
 
 int set_lds_limits() {
@@ -856,15 +900,21 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
     p.m = (int)m;
     p.N = (int)N;
 
+    static const bool overlap_env = getenv("BARK_NO_DIAG_OVERLAP") == nullptr;
+    Overlap *ov = nullptr;
+    if (overlap_env && (rc = get_overlap(&ov, (size_t)2 * p.nrb))) return rc;
+    hipStream_t panel_stream = ov ? ov->helper : stream;
+
     std::vector<hipEvent_t> ev;  // timing mode only: chunk marks + one event pair per factorisation launch
-    auto mark = [&]() -> int {
+    auto mark_on = [&](hipStream_t s) -> int {
         if (!timing) return BARK_OK;
         hipEvent_t e;
         BARK_HIP_CHECK(hipEventCreate(&e));
-        BARK_HIP_CHECK(hipEventRecord(e, stream));
+        BARK_HIP_CHECK(hipEventRecord(e, s));
         ev.push_back(e);
         return BARK_OK;
     };
+    auto mark = [&]() -> int { return mark_on(stream); };
     std::vector<size_t> gram_marks, chol_marks, diag_marks, panel_marks, solve_marks;
     double panel_flops = 0.0, solve_flops = 0.0;
 
@@ -905,27 +955,36 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
         if ((rc = mark())) return rc;  // end of gram == start of chol
 
         for (int j = 0; j < p.nrb; ++j) {
+            const int n_right = p.ncb - j - 1;
+            const int n_diag = (j + 1 < p.nrb) ? 1 : 0;
+            const bool has_panel = j >= 1 && n_right + n_diag > 0;
+            if (ov && has_panel) {  // fork: panel(j) waits for everything enqueued so far (solve(j-1))
+                BARK_HIP_CHECK(hipEventRecord(ov->events[2 * j], stream));
+                BARK_HIP_CHECK(hipStreamWaitEvent(panel_stream, ov->events[2 * j], 0));
+            }
             if (timing) diag_marks.push_back(ev.size());
             if ((rc = mark())) return rc;
             hipLaunchKernelGGL(diag_kernel, dim3((unsigned)bc), dim3(THREADS), DIAG_LDS, stream, p, j);
             BARK_LAUNCH_CHECK();
             if ((rc = mark())) return rc;
-            const int n_right = p.ncb - j - 1;
-            const int n_diag = (j + 1 < p.nrb) ? 1 : 0;
-            if (j >= 1 && n_right + n_diag > 0) {
+            if (has_panel) {
                 if (timing) panel_marks.push_back(ev.size());
-                if ((rc = mark())) return rc;
+                if ((rc = mark_on(panel_stream))) return rc;
                 const dim3 pg(xcd_grid(n_right + n_diag, (int)bc));
                 const size_t pl = GEMM_LDS + debug_extra_lds();
                 if (!fused)
-                    hipLaunchKernelGGL(panel_kernel<0>, pg, dim3(THREADS), pl, stream, p, j, n_right, n_right + n_diag);
+                    hipLaunchKernelGGL(panel_kernel<0>, pg, dim3(THREADS), pl, panel_stream, p, j, n_right, n_right + n_diag);
                 else if (seven)
-                    hipLaunchKernelGGL(panel_kernel<1>, pg, dim3(THREADS), pl, stream, p, j, n_right, n_right + n_diag);
+                    hipLaunchKernelGGL(panel_kernel<1>, pg, dim3(THREADS), pl, panel_stream, p, j, n_right, n_right + n_diag);
                 else
-                    hipLaunchKernelGGL(panel_kernel<2>, pg, dim3(THREADS), pl, stream, p, j, n_right, n_right + n_diag);
+                    hipLaunchKernelGGL(panel_kernel<2>, pg, dim3(THREADS), pl, panel_stream, p, j, n_right, n_right + n_diag);
                 BARK_LAUNCH_CHECK();
-                if ((rc = mark())) return rc;
+                if ((rc = mark_on(panel_stream))) return rc;
                 panel_flops += 2.0 * NB * NB * (double)(j * NB) * (double)(n_right + n_diag) * (double)bc;
+                if (ov) {  // join: solve(j) (and diag(j+1)) need the panel's tiles
+                    BARK_HIP_CHECK(hipEventRecord(ov->events[2 * j + 1], panel_stream));
+                    BARK_HIP_CHECK(hipStreamWaitEvent(stream, ov->events[2 * j + 1], 0));
+                }
             }
             if (n_right > 0) {
                 if (timing) solve_marks.push_back(ev.size());

@@ -169,8 +169,9 @@ def main():
         },
         "roofline": {
             "bound": "mfma",
-            "kernel": "Cholesky launch sequence per step (diag_kernel + panel_kernel + solve_kernel); "
-                      "panel_kernel dominates",
+            "kernel": "Cholesky launch sequence per step (diag_kernel + panel_kernel + solve_kernel; panel_kernel "
+                      "dominates). diag_kernel(j) runs concurrently with panel_kernel(j) on a second stream, so the "
+                      "per-kernel event spans below overlap and do not add up to chol_ms",
             "achieved": chol_tflops,
             "peak": F64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
