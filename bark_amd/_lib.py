@@ -32,8 +32,8 @@ class PackInfo(ctypes.Structure):
 
 class MllTiming(ctypes.Structure):
     _fields_ = [
-        ("gram_ms", ctypes.c_float), ("chol_ms", ctypes.c_float), ("diag_ms", ctypes.c_float),
-        ("panel_ms", ctypes.c_float), ("solve_ms", ctypes.c_float),
+        ("total_ms", ctypes.c_float), ("gram_ms", ctypes.c_float), ("chol_ms", ctypes.c_float),
+        ("diag_ms", ctypes.c_float), ("panel_ms", ctypes.c_float), ("solve_ms", ctypes.c_float),
         ("n_diag_launches", i64), ("n_panel_launches", i64), ("n_solve_launches", i64),
         ("panel_flops", ctypes.c_double), ("solve_flops", ctypes.c_double),
     ]

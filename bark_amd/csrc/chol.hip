@@ -786,33 +786,35 @@ size_t debug_extra_lds() {
     return (size_t)v;
 }
 
-// diag(j) and panel(j) both depend only on solve(j-1), so they run concurrently: diag stays on the
-// caller's stream (it is dispatched the moment solve(j-1) retires and claims one slot per CU; its 82 KiB
-// of LDS leave room for a panel workgroup beside it) and the panel kernel is forked onto a helper stream
-// and joined before solve(j) (events; capturable).  Latency-bound diag waves thus share CUs with
-// MFMA-bound panel waves instead of holding the whole chip for ~0.1 ms per block column.
-struct Overlap {
+// diag(j) and panel(j) both depend only on solve(j-1), so they run concurrently (speed only; every
+// kernel's inputs are ordered by events): diag stays on the caller's stream (it is dispatched the moment
+// solve(j-1) retires and claims one slot per CU; its 82 KiB of LDS leave room for a panel workgroup beside
+// it) and the panel kernel is forked onto a helper stream and joined before solve(j).  The helper stream
+// and the events are created once per device and reused; the pattern is fork/join, so it is capturable.
+// (Tried and rejected: splitting the resident matrices into two independently advancing lanes so that
+// one lane's panel kernel covers the other's diag/solve phases — 5 % slower at B = 256, 4 % at B = 64.)
+struct DeviceRes {
     hipStream_t helper = nullptr;
-    std::vector<hipEvent_t> events;
+    std::vector<hipEvent_t> events;  // 2 per block column (fork, join)
 };
 
-int get_overlap(Overlap **out, size_t n_events) {
-    static thread_local Overlap per_device[32];
+int get_device_res(DeviceRes **out, size_t n_events) {
+    static thread_local DeviceRes per_device[32];
     int dev = 0;
     BARK_HIP_CHECK(hipGetDevice(&dev));
     if (dev < 0 || dev >= 32) return fail(BARK_ERR_ARG, "device index %d out of range", dev);
-    Overlap &o = per_device[dev];
-    if (!o.helper) {
+    DeviceRes &r = per_device[dev];
+    if (!r.helper) {
         int lo = 0, hi = 0;
         BARK_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        BARK_HIP_CHECK(hipStreamCreateWithPriority(&o.helper, hipStreamNonBlocking, lo));
+        BARK_HIP_CHECK(hipStreamCreateWithPriority(&r.helper, hipStreamNonBlocking, lo));
     }
-    while (o.events.size() < n_events) {
+    while (r.events.size() < n_events) {
         hipEvent_t e;
         BARK_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        o.events.push_back(e);
+        r.events.push_back(e);
     }
-    *out = &o;
+    *out = &r;
     return BARK_OK;
 }
 
@@ -877,35 +879,46 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
     int rc = set_lds_limits();
     if (rc) return rc;
 
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    char *ws = static_cast<char *>(workspace);
-    Mats p;
-    p.A = reinterpret_cast<double *>(ws + L.off_A);
-    p.ld = L.ld;
-    p.bstride = L.npad * L.ld;
-    p.W = reinterpret_cast<double *>(ws + L.off_W);
-    p.yz = reinterpret_cast<double *>(ws + L.off_yz);
-    p.accum = reinterpret_cast<double *>(ws + L.off_acc);
-    p.nrb = (int)(L.npad / NB);
-    p.ncb = (int)(L.ncols / NB);
-    uint32_t *leafx = reinterpret_cast<uint32_t *>(ws + L.off_leafx);
-    uint32_t *leafc = reinterpret_cast<uint32_t *>(ws + L.off_leafc);
+    hipStream_t caller = static_cast<hipStream_t>(stream_);
     const bool seven = info->max_leaves <= 128;
     const bool use_scale = (flags & BARK_MLL_INCLUDE_SCALE) != 0;
     // MLL-only sweeps generate A inside the panel kernel; only block rows 0 and 1 are materialised
     // (inputs of diag(0), solve(0), diag(1)).  With candidates the whole matrix is filled up front.
     static const bool fuse_env = getenv("BARK_NO_FUSED_GRAM") == nullptr;
     const bool fused = fuse_env && C == 0 && (size_t)2 * L.W * NB * sizeof(uint32_t) <= GEMM_LDS;
-    p.nW = (int)L.W;
-    p.m = (int)m;
-    p.N = (int)N;
-
     static const bool overlap_env = getenv("BARK_NO_DIAG_OVERLAP") == nullptr;
-    Overlap *ov = nullptr;
-    if (overlap_env && (rc = get_overlap(&ov, (size_t)2 * p.nrb))) return rc;
-    hipStream_t panel_stream = ov ? ov->helper : stream;
+    const int nrb = (int)(L.npad / NB), ncb = (int)(L.ncols / NB);
+    DeviceRes *res = nullptr;
+    if (overlap_env && (rc = get_device_res(&res, (size_t)2 * nrb))) return rc;
 
-    std::vector<hipEvent_t> ev;  // timing mode only: chunk marks + one event pair per factorisation launch
+    struct Chunk {
+        Mats p;
+        uint32_t *leafx, *leafc;
+        hipStream_t main, panel;
+        int64_t c0, bc;
+    } ln;
+    {
+        char *ws = static_cast<char *>(workspace);
+        Mats &p = ln.p;
+        p.A = reinterpret_cast<double *>(ws + L.off_A);
+        p.ld = L.ld;
+        p.bstride = L.npad * L.ld;
+        p.W = reinterpret_cast<double *>(ws + L.off_W);
+        p.yz = reinterpret_cast<double *>(ws + L.off_yz);
+        p.accum = reinterpret_cast<double *>(ws + L.off_acc);
+        p.nrb = nrb;
+        p.ncb = ncb;
+        p.nW = (int)L.W;
+        p.m = (int)m;
+        p.N = (int)N;
+        ln.leafx = reinterpret_cast<uint32_t *>(ws + L.off_leafx);
+        ln.leafc = reinterpret_cast<uint32_t *>(ws + L.off_leafc);
+        ln.main = caller;
+        ln.panel = res ? res->helper : caller;
+    }
+
+    // timing mode only: one event pair per launch, on the stream of the launch
+    std::vector<hipEvent_t> ev;
     auto mark_on = [&](hipStream_t s) -> int {
         if (!timing) return BARK_OK;
         hipEvent_t e;
@@ -914,129 +927,150 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
         ev.push_back(e);
         return BARK_OK;
     };
-    auto mark = [&]() -> int { return mark_on(stream); };
-    std::vector<size_t> gram_marks, chol_marks, diag_marks, panel_marks, solve_marks;
+    std::vector<size_t> gram_marks, diag_marks, panel_marks, solve_marks;
     double panel_flops = 0.0, solve_flops = 0.0;
 
-    for (int64_t c0 = 0; c0 < B; c0 += Bc) {
-        const int64_t bc = (B - c0 < Bc) ? (B - c0) : Bc;
+    auto prologue = [&]() -> int {  // leaf walk, Gram fill, right-hand sides of one chunk
+        Mats &p = ln.p;
+        hipStream_t s = ln.main;
+        const int64_t c0 = ln.c0, bc = ln.bc;
         bark_pack_info sub = *info;
         sub.B = bc;
         const char *packed_c = static_cast<const char *>(packed) + (size_t)c0 * m * info->stride * 16;
         p.info = info_out + c0;
         p.Bc = (int)bc;
-
-        if (timing) gram_marks.push_back(ev.size());
-        if ((rc = mark())) return rc;
-        if ((rc = bark_leaf_bytes_hip(packed_c, &sub, X, N, d, leafx, stream))) return rc;
-        p.leafx = fused ? leafx : nullptr;
+        p.leafx = fused ? ln.leafx : nullptr;
         p.scale = use_scale ? scale + c0 : nullptr;
         p.shift = shift ? shift + c0 : nullptr;
         p.noise = noise + c0;
+        int r;
+        if (timing) gram_marks.push_back(ev.size());
+        if ((r = mark_on(s))) return r;
+        if ((r = bark_leaf_bytes_hip(packed_c, &sub, X, N, d, ln.leafx, s))) return r;
         const int fill_rows = fused ? (int)(L.npad < 2 * NB ? L.npad : 2 * NB) : (int)L.npad;
-        rc = launch_gram(leafx, (int)L.npad, leafx, (int)L.npad, bc, m, (int)N, (int)N, fill_rows, (int)L.npad,
-                         p.shift, use_scale ? scale + c0 : nullptr, noise + c0, p.A, L.ld, p.bstride, true, true, seven, stream);
-        if (rc) return rc;
+        r = launch_gram(ln.leafx, (int)L.npad, ln.leafx, (int)L.npad, bc, m, (int)N, (int)N, fill_rows, (int)L.npad,
+                        p.shift, p.scale, p.noise, p.A, L.ld, p.bstride, true, true, seven, s);
+        if (r) return r;
         if (rhs_identity) {
             dim3 g((unsigned)((L.cpad + 255) / 256), (unsigned)L.npad, (unsigned)bc);
-            hipLaunchKernelGGL(identity_rhs_kernel, g, dim3(256), 0, stream, p, (int)N, (int)L.cpad);
+            hipLaunchKernelGGL(identity_rhs_kernel, g, dim3(256), 0, s, p, (int)N, (int)L.cpad);
             BARK_LAUNCH_CHECK();
         } else if (C > 0) {
-            if ((rc = bark_leaf_bytes_hip(packed_c, &sub, cand, C, d, leafc, stream))) return rc;
-            rc = launch_gram(leafx, (int)L.npad, leafc, (int)L.cpad, bc, m, (int)N, (int)C, (int)L.npad, (int)L.cpad,
-                             p.shift, scale + c0, nullptr, p.A + L.npad, L.ld, p.bstride, false, false, seven, stream);
-            if (rc) return rc;
+            if ((r = bark_leaf_bytes_hip(packed_c, &sub, cand, C, d, ln.leafc, s))) return r;
+            r = launch_gram(ln.leafx, (int)L.npad, ln.leafc, (int)L.cpad, bc, m, (int)N, (int)C, (int)L.npad,
+                            (int)L.cpad, p.shift, scale + c0, nullptr, p.A + L.npad, L.ld, p.bstride, false, false, seven, s);
+            if (r) return r;
         }
-        {
-            dim3 g((unsigned)((L.npad + 255) / 256), (unsigned)bc);
-            hipLaunchKernelGGL(init_rhs_kernel, g, dim3(256), 0, stream, y, (int)N, (int)L.npad, p.yz, p.accum, p.info);
-            BARK_LAUNCH_CHECK();
-        }
-        if ((rc = mark())) return rc;  // end of gram == start of chol
+        dim3 g((unsigned)((L.npad + 255) / 256), (unsigned)bc);
+        hipLaunchKernelGGL(init_rhs_kernel, g, dim3(256), 0, s, y, (int)N, (int)L.npad, p.yz, p.accum, p.info);
+        BARK_LAUNCH_CHECK();
+        return mark_on(s);
+    };
 
-        for (int j = 0; j < p.nrb; ++j) {
-            const int n_right = p.ncb - j - 1;
-            const int n_diag = (j + 1 < p.nrb) ? 1 : 0;
-            const bool has_panel = j >= 1 && n_right + n_diag > 0;
-            if (ov && has_panel) {  // fork: panel(j) waits for everything enqueued so far (solve(j-1))
-                BARK_HIP_CHECK(hipEventRecord(ov->events[2 * j], stream));
-                BARK_HIP_CHECK(hipStreamWaitEvent(panel_stream, ov->events[2 * j], 0));
-            }
-            if (timing) diag_marks.push_back(ev.size());
-            if ((rc = mark())) return rc;
-            hipLaunchKernelGGL(diag_kernel, dim3((unsigned)bc), dim3(THREADS), DIAG_LDS, stream, p, j);
+    auto step = [&](int j) -> int {  // block column j of one chunk: diag || panel, then solve
+        Mats &p = ln.p;
+        hipStream_t s = ln.main, ps = ln.panel;
+        const int bc = (int)ln.bc;
+        const int n_right = ncb - j - 1;
+        const int n_diag = (j + 1 < nrb) ? 1 : 0;
+        const bool has_panel = j >= 1 && n_right + n_diag > 0;
+        const bool forked = ps != s;
+        int r;
+        if (forked && has_panel) {  // fork: panel(j) waits for everything enqueued so far (solve(j-1))
+            BARK_HIP_CHECK(hipEventRecord(res->events[2 * j], s));
+            BARK_HIP_CHECK(hipStreamWaitEvent(ps, res->events[2 * j], 0));
+        }
+        if (timing) diag_marks.push_back(ev.size());
+        if ((r = mark_on(s))) return r;
+        hipLaunchKernelGGL(diag_kernel, dim3((unsigned)bc), dim3(THREADS), DIAG_LDS, s, p, j);
+        BARK_LAUNCH_CHECK();
+        if ((r = mark_on(s))) return r;
+        if (has_panel) {
+            if (timing) panel_marks.push_back(ev.size());
+            if ((r = mark_on(ps))) return r;
+            const dim3 pg(xcd_grid(n_right + n_diag, bc));
+            const size_t pl = GEMM_LDS + debug_extra_lds();
+            if (!fused)
+                hipLaunchKernelGGL(panel_kernel<0>, pg, dim3(THREADS), pl, ps, p, j, n_right, n_right + n_diag);
+            else if (seven)
+                hipLaunchKernelGGL(panel_kernel<1>, pg, dim3(THREADS), pl, ps, p, j, n_right, n_right + n_diag);
+            else
+                hipLaunchKernelGGL(panel_kernel<2>, pg, dim3(THREADS), pl, ps, p, j, n_right, n_right + n_diag);
             BARK_LAUNCH_CHECK();
-            if ((rc = mark())) return rc;
-            if (has_panel) {
-                if (timing) panel_marks.push_back(ev.size());
-                if ((rc = mark_on(panel_stream))) return rc;
-                const dim3 pg(xcd_grid(n_right + n_diag, (int)bc));
-                const size_t pl = GEMM_LDS + debug_extra_lds();
-                if (!fused)
-                    hipLaunchKernelGGL(panel_kernel<0>, pg, dim3(THREADS), pl, panel_stream, p, j, n_right, n_right + n_diag);
-                else if (seven)
-                    hipLaunchKernelGGL(panel_kernel<1>, pg, dim3(THREADS), pl, panel_stream, p, j, n_right, n_right + n_diag);
-                else
-                    hipLaunchKernelGGL(panel_kernel<2>, pg, dim3(THREADS), pl, panel_stream, p, j, n_right, n_right + n_diag);
-                BARK_LAUNCH_CHECK();
-                if ((rc = mark_on(panel_stream))) return rc;
-                panel_flops += 2.0 * NB * NB * (double)(j * NB) * (double)(n_right + n_diag) * (double)bc;
-                if (ov) {  // join: solve(j) (and diag(j+1)) need the panel's tiles
-                    BARK_HIP_CHECK(hipEventRecord(ov->events[2 * j + 1], panel_stream));
-                    BARK_HIP_CHECK(hipStreamWaitEvent(stream, ov->events[2 * j + 1], 0));
-                }
-            }
-            if (n_right > 0) {
-                if (timing) solve_marks.push_back(ev.size());
-                if ((rc = mark())) return rc;
-                hipLaunchKernelGGL(solve_kernel, dim3(xcd_grid(n_right, (int)bc)), dim3(THREADS), GEMM_LDS, stream, p, j,
-                                   n_right);
-                BARK_LAUNCH_CHECK();
-                if ((rc = mark())) return rc;
-                solve_flops += 2.0 * NB * NB * (double)NB * (double)n_right * (double)bc;
+            if ((r = mark_on(ps))) return r;
+            panel_flops += 2.0 * NB * NB * (double)(j * NB) * (double)(n_right + n_diag) * (double)bc;
+            if (forked) {  // join: solve(j) (and diag(j+1)) need the panel's tiles
+                BARK_HIP_CHECK(hipEventRecord(res->events[2 * j + 1], ps));
+                BARK_HIP_CHECK(hipStreamWaitEvent(s, res->events[2 * j + 1], 0));
             }
         }
-        hipLaunchKernelGGL(finish_mll_kernel, dim3((unsigned)((bc + 255) / 256)), dim3(256), 0, stream, p.accum, (int)bc,
-                           (int)N, (flags & BARK_MLL_INCLUDE_2PI) ? 1 : 0, mll_out + c0);
+        if (n_right > 0) {
+            if (timing) solve_marks.push_back(ev.size());
+            if ((r = mark_on(s))) return r;
+            hipLaunchKernelGGL(solve_kernel, dim3(xcd_grid(n_right, bc)), dim3(THREADS), GEMM_LDS, s, p, j, n_right);
+            BARK_LAUNCH_CHECK();
+            if ((r = mark_on(s))) return r;
+            solve_flops += 2.0 * NB * NB * (double)NB * (double)n_right * (double)bc;
+        }
+        return BARK_OK;
+    };
+
+    auto epilogue = [&]() -> int {  // MLL and posterior reductions of one chunk
+        Mats &p = ln.p;
+        hipStream_t s = ln.main;
+        const int64_t c0 = ln.c0, bc = ln.bc;
+        hipLaunchKernelGGL(finish_mll_kernel, dim3((unsigned)((bc + 255) / 256)), dim3(256), 0, s, p.accum, (int)bc, (int)N,
+                           (flags & BARK_MLL_INCLUDE_2PI) ? 1 : 0, mll_out + c0);
         BARK_LAUNCH_CHECK();
         if (C > 0) {
             dim3 g((unsigned)((C + 255) / 256), (unsigned)bc);
-            hipLaunchKernelGGL(predict_reduce_kernel, g, dim3(256), 0, stream, p, (int)N, (int)C,
+            hipLaunchKernelGGL(predict_reduce_kernel, g, dim3(256), 0, s, p, (int)N, (int)C,
                                rhs_identity ? nullptr : scale + c0, mu_out + (size_t)c0 * C,
                                var_out ? var_out + (size_t)c0 * C : nullptr);
             BARK_LAUNCH_CHECK();
             if (cov_out) {
                 const int nct = (int)(L.cpad / NB);
-                hipLaunchKernelGGL(vtv_kernel, dim3(xcd_grid(nct * nct, (int)bc)), dim3(THREADS), GEMM_LDS, stream, p, nct,
+                hipLaunchKernelGGL(vtv_kernel, dim3(xcd_grid(nct * nct, (int)bc)), dim3(THREADS), GEMM_LDS, s, p, nct,
                                    (int)C, rhs_identity ? nullptr : scale + c0, rhs_identity ? 1.0 : -1.0,
                                    rhs_identity ? 1 : 0, cov_out + (size_t)c0 * C * C);
                 BARK_LAUNCH_CHECK();
             }
         }
-        if (timing) chol_marks.push_back(ev.size());
-        if ((rc = mark())) return rc;
+        return BARK_OK;
+    };
+
+    const size_t t_begin = ev.size();
+    if ((rc = mark_on(caller))) return rc;
+    for (int64_t c0 = 0; c0 < B; c0 += Bc) {  // chunks of Bc resident matrices, one after the other
+        ln.c0 = c0;
+        ln.bc = (B - c0 < Bc) ? (B - c0) : Bc;
+        if ((rc = prologue())) return rc;
+        for (int j = 0; j < nrb; ++j)
+            if ((rc = step(j))) return rc;
+        if ((rc = epilogue())) return rc;
     }
+    const size_t t_end = ev.size();
+    if ((rc = mark_on(caller))) return rc;
 
     if (timing) {
-        BARK_HIP_CHECK(hipStreamSynchronize(stream));
+        BARK_HIP_CHECK(hipStreamSynchronize(caller));
         auto span = [&](size_t a, size_t b_, float *acc) -> int {
             float ms = 0.f;
             BARK_HIP_CHECK(hipEventElapsedTime(&ms, ev[a], ev[b_]));
             *acc += ms;
             return BARK_OK;
         };
-        timing->gram_ms = timing->chol_ms = timing->diag_ms = timing->panel_ms = timing->solve_ms = 0.f;
-        for (size_t k = 0; k < gram_marks.size(); ++k) {
-            // chunk k: events [g0, g1 (== chol start), (panel pairs...), chol end]
-            if ((rc = span(gram_marks[k], gram_marks[k] + 1, &timing->gram_ms))) return rc;
-            if ((rc = span(gram_marks[k] + 1, chol_marks[k], &timing->chol_ms))) return rc;
-        }
+        timing->total_ms = timing->gram_ms = timing->chol_ms = timing->diag_ms = timing->panel_ms = timing->solve_ms = 0.f;
+        if ((rc = span(t_begin, t_end, &timing->total_ms))) return rc;
+        for (size_t a : gram_marks)
+            if ((rc = span(a, a + 1, &timing->gram_ms))) return rc;
         for (size_t a : diag_marks)
             if ((rc = span(a, a + 1, &timing->diag_ms))) return rc;
         for (size_t a : panel_marks)
             if ((rc = span(a, a + 1, &timing->panel_ms))) return rc;
         for (size_t a : solve_marks)
             if ((rc = span(a, a + 1, &timing->solve_ms))) return rc;
+        timing->chol_ms = timing->total_ms - timing->gram_ms;
         timing->n_diag_launches = (int64_t)diag_marks.size();
         timing->n_panel_launches = (int64_t)panel_marks.size();
         timing->n_solve_launches = (int64_t)solve_marks.size();

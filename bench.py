@@ -21,7 +21,6 @@ from __future__ import annotations
 import argparse
 import ctypes
 import json
-import math
 import os
 import sys
 import time
@@ -107,7 +106,7 @@ def main():
     flags = _lib.MLL_INCLUDE_2PI
     stream = _lib.stream_ptr()
     timing = _lib.MllTiming()
-    tsum = dict(gram_ms=0.0, chol_ms=0.0, diag_ms=0.0, panel_ms=0.0, solve_ms=0.0)
+    tsum = dict(total_ms=0.0, gram_ms=0.0, chol_ms=0.0, diag_ms=0.0, panel_ms=0.0, solve_ms=0.0)
 
     def step(timed: bool):
         _lib.check(lib.bark_mll_batched_hip(
@@ -170,8 +169,8 @@ def main():
         "roofline": {
             "bound": "mfma",
             "kernel": "Cholesky launch sequence per step (diag_kernel + panel_kernel + solve_kernel; panel_kernel "
-                      "dominates). diag_kernel(j) runs concurrently with panel_kernel(j) on a second stream, so the "
-                      "per-kernel event spans below overlap and do not add up to chol_ms",
+                      "dominates). diag_kernel(j) runs beside panel_kernel(j) on a helper stream, so the per-kernel "
+                      "event spans below overlap and do not add up to chol_ms",
             "achieved": chol_tflops,
             "peak": F64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
@@ -217,7 +216,7 @@ def main():
         result["cpu_baseline"] = {
             "value": ns / cpu_s,
             "unit": "evals/s",
-            "cores": os.cpu_count(),
+            "cores": len(os.sched_getaffinity(0)),
             "kind": "port",
             "sample": "%d of the %d forest samples of this workload (N=%d): C leaf walk + N*N*m compare-count Gram "
                       "(1 thread, as the reference) + numpy.linalg.inv + slogdet (LAPACK threads = cores), %.1f s"

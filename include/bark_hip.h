@@ -126,14 +126,15 @@ int bark_gram_from_leaves_hip(const uint32_t *leaf1, int64_t N, const uint32_t *
  * consumes.  `shift` (B,) or NULL subtracts n_null/m before scaling (forest.py:102-111 no-null kernel).
  *
  * workspace: device buffer of at least bark_mll_workspace_bytes(N, C, m, Bc) bytes, where Bc
- * (1 <= Bc <= B) is the number of forests factorised concurrently; B is processed in chunks of Bc.
+ * (1 <= Bc <= B) is the number of forests resident / factorised concurrently; B is processed in chunks of Bc.
  * info_out (device, B int32): 0, or 1-based index of the first non-positive pivot (not PD).
  * ------------------------------------------------------------------------------------- */
 size_t bark_mll_workspace_bytes(int64_t N, int64_t C, int64_t m, int64_t Bc);
 
 typedef struct {
-    float gram_ms;      /* leaf traversal + Gram fill + rhs init of the chunk(s) */
-    float chol_ms;      /* every factorisation launch: diag + panel + solve kernels, finish, predict reduce */
+    float total_ms;     /* the whole call on the caller's stream */
+    float gram_ms;      /* leaf traversal + Gram fill + rhs init, summed over chunks */
+    float chol_ms;      /* factorisation sequence (diag + panel + solve, finish, reductions) = total - gram */
     float diag_ms;      /* of which: diag_kernel  (128x128 potrf + inverse + z_j)            */
     float panel_ms;     /* of which: panel_kernel (fp64 MFMA trailing-panel update, K = 128 j) */
     float solve_ms;     /* of which: solve_kernel (MFMA triangular solve by the block inverse) */
