@@ -258,15 +258,23 @@ __device__ __forceinline__ void gemm_upper_tri(f64x4 (&acc)[4][4], const int (&r
 // XCDs (id % 8 labels the XCD group; speed only, never correctness), and every tile of block row j of
 // one matrix streams the same A panel U[0:128j, j]: give all tiles of matrix b ids == b (mod 8), in one
 // contiguous run of the per-XCD sequence, so that panel is fetched into ONE 4 MiB L2 once and shared.
-// Grid = 8 * ceil(Bc/8) * ntiles; ids whose matrix is >= Bc exit.
+// With fewer than 8 resident matrices that would leave XCDs idle, so each matrix is split into
+// R = ceil(8 / Bc) "virtual matrices" holding every R-th tile; virtual matrix v goes to XCD v % 8.
+// Grid = 8 * ceil(Bc R / 8) * ceil(ntiles / R); ids that fall outside exit.
 constexpr int NXCD = 8;
+__host__ __device__ __forceinline__ int xcd_rep(int Bc) { return Bc >= NXCD ? 1 : (NXCD + Bc - 1) / Bc; }
 __device__ __forceinline__ bool xcd_map(int id, int ntiles, int Bc, int &b, int &tile) {
+    const int R = xcd_rep(Bc), ntv = (ntiles + R - 1) / R;
     const int x = id % NXCD, q = id / NXCD;
-    b = (q / ntiles) * NXCD + x;
-    tile = q % ntiles;
-    return b < Bc;
+    const int v = (q / ntv) * NXCD + x;  // virtual matrix
+    b = v / R;
+    tile = (q % ntv) * R + (v - b * R);
+    return b < Bc && tile < ntiles;
 }
-inline unsigned xcd_grid(int ntiles, int Bc) { return (unsigned)(NXCD * ((Bc + NXCD - 1) / NXCD) * ntiles); }
+inline unsigned xcd_grid(int ntiles, int Bc) {
+    const int R = xcd_rep(Bc), ntv = (ntiles + R - 1) / R;
+    return (unsigned)(NXCD * ((Bc * R + NXCD - 1) / NXCD) * ntv);
+}
 
 struct Mats {
     double *A;            // (Bc, Npad, ld)
@@ -585,6 +593,51 @@ __global__ __launch_bounds__(THREADS, 2) void panel_kernel(Mats p, int j, int n_
 }
 
 // ---------------------------------------------------------------------------------------------
+// Split-K variant of the panel update for under-filled steps (few matrices x few tiles, e.g. one
+// N = 16384 matrix): the K = 128 j range of every tile is cut into S contiguous slabs, each accumulated by
+// its own workgroup into a scratch slab; panel_reduce_kernel then forms T = A - sum_s slab_s in a fixed
+// order (deterministic, unlike atomics).  Tile index t' = tile * S + s.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(Mats p, int j, int n_right, int n_tiles, int S,
+                                                                  double *slabs) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x;
+    int b, ts;
+    if (!xcd_map(blockIdx.x, n_tiles * S, p.Bc, b, ts)) return;
+    const Lane q = lane_of(tid);
+    const int t = ts / S, s = ts - t * S;
+    const int rb = t < n_right ? j : j + 1, cb = t < n_right ? j + 1 + t : j + 1;
+    const int kb0 = (int)(((long)j * s) / S), kb1 = (int)(((long)j * (s + 1)) / S);  // block rows [kb0, kb1)
+    const double *Ab = p.A + (size_t)b * p.bstride + (size_t)kb0 * NB * p.ld;
+    f64x4 acc[4][4];
+    zero_acc(acc);
+    gemm_kmajor_dma(acc, Ab + (size_t)rb * NB, p.ld, Ab + (size_t)cb * NB, p.ld, (kb1 - kb0) * NB, lds, tid, q);
+    double *slab = slabs + ((size_t)((size_t)b * n_tiles + t) * S + s) * NB * NB;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            double *row = slab + (size_t)acc_row(q, mt, v) * NB;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) row[acc_col(q, nt)] = acc[mt][nt][v];
+        }
+}
+
+__global__ __launch_bounds__(THREADS) void panel_reduce_kernel(Mats p, int j, int n_right, int n_tiles, int S,
+                                                               const double *slabs) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    const int rb = t < n_right ? j : j + 1, cb = t < n_right ? j + 1 + t : j + 1;
+    double *tile = p.A + (size_t)b * p.bstride + (size_t)rb * NB * p.ld + (size_t)cb * NB;
+    const double *slab = slabs + (size_t)((size_t)b * n_tiles + t) * S * NB * NB;
+    for (int e = threadIdx.x; e < NB * NB; e += THREADS) {
+        double sum = 0.0;
+        for (int s = 0; s < S; ++s) sum += slab[(size_t)s * NB * NB + e];
+        double *dst = tile + (size_t)(e >> 7) * p.ld + (e & (NB - 1));
+        *dst = *dst - sum;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // solve_kernel: U[j,i] = W_j' T[j,i] for every tile right of the diagonal; y_i -= U[j,i]' z_j.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(THREADS, 2) void solve_kernel(Mats p, int j, int n_right) {
@@ -741,9 +794,13 @@ __global__ __launch_bounds__(THREADS) void quadform_kernel(const double *__restr
     if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
+constexpr int SPLITK_SLOTS = 512;  // workgroup slots split-K aims to fill (2 per CU)
+constexpr int SPLITK_MAX = 16;
+
 struct Layout {
     int64_t npad, cpad, ncols, ld, W;
-    size_t off_A, off_W, off_yz, off_acc, off_leafx, off_leafc, total;
+    bool splitk;  // chunk too small to fill the chip with one workgroup per tile: slab scratch reserved
+    size_t off_A, off_W, off_yz, off_acc, off_leafx, off_leafc, off_slab, total;
 };
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -768,6 +825,9 @@ Layout make_layout(int64_t N, int64_t C, int64_t m, int64_t Bc) {
     o = align256(o + (size_t)Bc * L.W * L.npad * sizeof(uint32_t));
     L.off_leafc = o;
     o = align256(o + (size_t)Bc * L.W * L.cpad * sizeof(uint32_t));
+    L.off_slab = o;
+    L.splitk = Bc * (L.ncols / NB) < SPLITK_SLOTS / 2 && L.npad / NB >= 4;
+    if (L.splitk) o = align256(o + (size_t)(SPLITK_SLOTS + SPLITK_MAX * Bc) * NB * NB * sizeof(double));
     L.total = o;
     return L;
 }
@@ -829,6 +889,8 @@ int set_lds_limits() {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS + debug_extra_lds())));
     BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(panel_kernel<2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS + debug_extra_lds())));
+    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(panel_split_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
     BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(vtv_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
     BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(solve_kernel),
@@ -885,7 +947,10 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
     // MLL-only sweeps generate A inside the panel kernel; only block rows 0 and 1 are materialised
     // (inputs of diag(0), solve(0), diag(1)).  With candidates the whole matrix is filled up front.
     static const bool fuse_env = getenv("BARK_NO_FUSED_GRAM") == nullptr;
-    const bool fused = fuse_env && C == 0 && (size_t)2 * L.W * NB * sizeof(uint32_t) <= GEMM_LDS;
+    static const bool splitk_env = getenv("BARK_NO_SPLITK") == nullptr;
+    const bool splitk = L.splitk && splitk_env;  // then A is materialised (the reduce kernel reads it)
+    const bool fused = fuse_env && !splitk && C == 0 && (size_t)2 * L.W * NB * sizeof(uint32_t) <= GEMM_LDS;
+    double *slabs = reinterpret_cast<double *>(static_cast<char *>(workspace) + L.off_slab);
     static const bool overlap_env = getenv("BARK_NO_DIAG_OVERLAP") == nullptr;
     const int nrb = (int)(L.npad / NB), ncb = (int)(L.ncols / NB);
     DeviceRes *res = nullptr;
@@ -988,9 +1053,22 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
         if (has_panel) {
             if (timing) panel_marks.push_back(ev.size());
             if ((r = mark_on(ps))) return r;
-            const dim3 pg(xcd_grid(n_right + n_diag, bc));
+            const int n_tiles = n_right + n_diag;
+            const dim3 pg(xcd_grid(n_tiles, bc));
             const size_t pl = GEMM_LDS + debug_extra_lds();
-            if (!fused)
+            int S = 1;  // split-K factor: fill ~SPLITK_SLOTS workgroup slots, >= 1 block row per slab
+            if (splitk && n_tiles * bc < SPLITK_SLOTS / 2) {
+                S = SPLITK_SLOTS / (n_tiles * bc);
+                if (S > j) S = j;
+                if (S > SPLITK_MAX) S = SPLITK_MAX;
+            }
+            if (S > 1) {
+                hipLaunchKernelGGL(panel_split_kernel, dim3(xcd_grid(n_tiles * S, bc)), dim3(THREADS), GEMM_LDS, ps, p, j,
+                                   n_right, n_tiles, S, slabs);
+                BARK_LAUNCH_CHECK();
+                hipLaunchKernelGGL(panel_reduce_kernel, dim3((unsigned)n_tiles, (unsigned)bc), dim3(THREADS), 0, ps, p, j,
+                                   n_right, n_tiles, S, slabs);
+            } else if (!fused)
                 hipLaunchKernelGGL(panel_kernel<0>, pg, dim3(THREADS), pl, ps, p, j, n_right, n_right + n_diag);
             else if (seven)
                 hipLaunchKernelGGL(panel_kernel<1>, pg, dim3(THREADS), pl, ps, p, j, n_right, n_right + n_diag);

@@ -51,10 +51,17 @@ def choose_chunk(B: int, N: int, C: int, m: int, budget_bytes: int | None = None
             free, _total = torch.cuda.mem_get_info()
             cached = _lib._workspace.numel() if _lib._workspace is not None else 0
             budget_bytes = int(0.7 * (free + cached))
-    one = int(lib.bark_mll_workspace_bytes(N, C, m, 1))
-    per = max(int(lib.bark_mll_workspace_bytes(N, C, m, 2)) - one, 1)
-    bc = 1 + max(0, (budget_bytes - one) // per)
-    return int(max(1, min(B, bc)))
+    need = lambda k: int(lib.bark_mll_workspace_bytes(N, C, m, k))  # noqa: E731
+    if need(B) <= budget_bytes:
+        return int(B)
+    lo, hi = 1, int(B)  # largest chunk whose workspace fits (need() is monotone)
+    while lo < hi:
+        mid = (lo + hi + 1) // 2
+        if need(mid) <= budget_bytes:
+            lo = mid
+        else:
+            hi = mid - 1
+    return lo
 
 
 def _run(forest, noise, scale, X, y, feat_types, flags, cand=None, timing=None, chunk=None, shift=None,

@@ -118,9 +118,10 @@ def test_packer_rejects_malformed_trees():
 def test_workspace_size_is_linear_in_chunk():
     lib = _lib.lib()
     one = lib.bark_mll_workspace_bytes(4096, 0, 50, 1)
-    two = lib.bark_mll_workspace_bytes(4096, 0, 50, 2)
-    many = lib.bark_mll_workspace_bytes(4096, 0, 50, 256)
-    assert one >= 4096 * 4096 * 8 and abs((many - one) - 255 * (two - one)) <= 256 * 1024
+    a, b2, many = (lib.bark_mll_workspace_bytes(4096, 0, 50, k) for k in (64, 128, 256))
+    assert one >= 4096 * 4096 * 8 and abs((many - b2) - 2 * (b2 - a)) <= 256 * 1024
+    sizes = [lib.bark_mll_workspace_bytes(4096, 0, 50, k) for k in range(1, 40)]
+    assert all(y > x for x, y in zip(sizes, sizes[1:]))  # monotone (small chunks also carry split-K scratch)
     assert lib.bark_mll_workspace_bytes(0, 0, 50, 1) == 0
     assert lib.bark_mll_workspace_bytes(1000, 500, 50, 3) > lib.bark_mll_workspace_bytes(1000, 0, 50, 3)
 
