@@ -26,7 +26,7 @@ def _dev(a):
     return t.to(torch.float64).contiguous()
 
 
-def _update(K_inv, U, subtract, want_inv, want_det):
+def _update(K_inv, U, subtract, want_inv, want_det, symmetric=False):
     import torch
 
     lib = _lib.lib()
@@ -39,15 +39,18 @@ def _update(K_inv, U, subtract, want_inv, want_det):
     ws = torch.empty(int(lib.bark_lowrank_workspace_bytes(N, r)), dtype=torch.uint8, device=Kd.device)
     out = torch.empty_like(Kd) if want_inv else None
     det = torch.empty(1, dtype=torch.float64, device=Kd.device) if want_det else None
-    _lib.check(lib.bark_lowrank_update_hip(_lib.ptr(Kd), N, _lib.ptr(Ud), r, 1 if subtract else 0, 0,
+    _lib.check(lib.bark_lowrank_update_hip(_lib.ptr(Kd), N, _lib.ptr(Ud), r, 1 if subtract else 0, 1 if symmetric else 0,
                                            _lib.ptr(out), _lib.ptr(det), _lib.ptr(ws), ws.numel(),
                                            _lib.stream_ptr()))
     return out, det
 
 
-def low_rank_inv_update(K_inv, U, subtract: bool = False):
-    """quick_inverse.py:13-21: K_inv - K_inv U (mul I + U' K_inv U)^-1 U' K_inv, mul = -1 if subtract."""
-    out, _ = _update(K_inv, U, subtract, True, False)
+def low_rank_inv_update(K_inv, U, subtract: bool = False, *, assume_symmetric: bool = False):
+    """quick_inverse.py:13-21: K_inv - K_inv U (mul I + U' K_inv U)^-1 U' K_inv, mul = -1 if subtract.
+
+    `assume_symmetric=True` (additive keyword) promises K_inv == K_inv' — true for every call of the
+    sampler (bark_sampler.py:242-255) — and reuses K_inv U as (U' K_inv)', saving one pass over K_inv."""
+    out, _ = _update(K_inv, U, subtract, True, False, symmetric=assume_symmetric)
     return out if _is_torch(K_inv) else out.cpu().numpy()
 
 

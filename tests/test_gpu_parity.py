@@ -193,6 +193,22 @@ def test_deep_trees_and_many_leaves(B):
     assert np.array_equal(B.bf.pass_through_forest(too_wide, X, ft), B.orc.pass_through_forest(too_wide, X, ft))
 
 
+def test_wide_feature_matrix_walks_from_global_memory(B):
+    """d = 40 > 31: the point rows no longer fit the walk kernel's LDS tile (leaf_walk_kernel<., false>)."""
+    rng = np.random.default_rng(40)
+    d, N = 40, 333
+    X = rng.uniform(size=(N, d))
+    ft = np.full(d, 2)
+    ft[[3, 17]] = 0
+    X[:, [3, 17]] = rng.integers(0, 5, size=(N, 2))
+    bounds = np.tile([[0.0, 1.0]], (d, 1))
+    bounds[[3, 17]] = [0.0, 31.0]
+    F = B.syn.sample_prior_forests(2, 20, bounds, ft, seed=40, alpha=0.95, beta=1.0)
+    for b in range(2):
+        assert np.array_equal(B.bf.pass_through_forest(F[b], X, ft), B.orc.pass_through_forest(F[b], X, ft))
+    assert np.array_equal(B.bf.batched_forest_gram_matrix(F, X, X, ft), B.orc.batched_forest_gram_matrix(F, X, X, ft))
+
+
 def test_posterior_against_oracle_ragged(B):
     X, y, bounds, ft = B.syn.mixed_problem(300, seed=9)
     cand, _, _, _ = B.syn.mixed_problem(257, seed=10)
@@ -288,10 +304,32 @@ def test_woodbury_large_against_oracle(B):
             got = qi.low_rank_inv_update(K_inv, U, subtract=sub)
             want = B.orc.low_rank_inv_update(K_inv, U, subtract=sub)
             assert np.allclose(got, want, rtol=1e-9, atol=1e-11)
+            fast = qi.low_rank_inv_update(K_inv, U, subtract=sub, assume_symmetric=True)
+            assert np.allclose(fast, want, rtol=1e-9, atol=1e-11)
             assert np.isclose(qi.low_rank_det_update(K_inv, U, logdet, subtract=sub),
                               B.orc.low_rank_det_update(K_inv, U, logdet, subtract=sub), rtol=1e-12)
     with pytest.raises(ValueError):
         qi.low_rank_inv_update(K_inv, rng.standard_normal((N, 65)))
+
+
+def test_single_large_matrix_split_k_path(B):
+    """B = 1 and B = 3 at N = 2100 (17 block rows): under-filled steps take the split-K panel path
+    (panel_split_kernel + panel_reduce_kernel) and tiles are interleaved over the XCDs."""
+    X, y, bounds, ft = B.syn.mixed_problem(2100, seed=21)
+    cand, _, _, _ = B.syn.mixed_problem(150, seed=22)
+    F = B.syn.sample_prior_forests(3, 50, bounds, ft, seed=21)
+    noise, scale = np.array([0.1, 0.05, 0.2]), np.array([1.0, 0.8, 1.3])
+    want = B.orc.batched_mll(F, noise, scale, X, y, ft, include_scale=True, include_2pi=True)
+    for nb in (1, 3):
+        got = B.fit.batched_mll(F[:nb], noise[:nb], scale[:nb], X, y, ft, include_scale=True, include_2pi=True)
+        assert np.allclose(got, want[:nb], rtol=MLL_RTOL, atol=MLL_ATOL), (nb, got, want)
+    mu, var = B.tk.forest_predict((F[:1], noise[:1], scale[:1]), (X, y), cand, ft)
+    mu0, var0 = B.orc.forest_predict((F[:1], noise[:1], scale[:1]), (X, y), cand, ft)
+    assert np.allclose(mu, mu0, rtol=1e-9, atol=1e-9) and np.allclose(var, var0, rtol=1e-9, atol=1e-9)
+    # same call twice: bit-identical (slabs are reduced in a fixed order, no atomics)
+    again = B.fit.batched_mll(F[:1], noise[:1], scale[:1], X, y, ft, include_scale=True, include_2pi=True)
+    first = B.fit.batched_mll(F[:1], noise[:1], scale[:1], X, y, ft, include_scale=True, include_2pi=True)
+    assert np.array_equal(again, first)
 
 
 def test_not_positive_definite_raises(B):
