@@ -3,7 +3,7 @@
    c1: TreeFunction N=64 single forest (MLL value parity, us/eval)
    c2: N=1024 d=8 m=50 single forest
    c5: N=16384 mixed cat+int+cont, 10k-candidate posterior predictive, B=1 (oracle check: Cholesky route on CPU)
-Run on the GPU box:  python tools/run_configs.py [--skip-c5-oracle]"""
+Not collected by pytest (no test_ prefix); run on the GPU box:  python tests/validate_configs.py [--skip-c5-oracle]"""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
