@@ -26,7 +26,7 @@ i64, vp, ci = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int
 class PackInfo(ctypes.Structure):
     _fields_ = [
         ("B", i64), ("m", i64), ("L", i64), ("stride", i64),
-        ("max_leaves", i64), ("max_depth", i64), ("packed_bytes", i64),
+        ("max_leaves", i64), ("max_depth", i64), ("packed_bytes", i64), ("max_bits", i64),
     ]
 
 
@@ -47,8 +47,10 @@ SIGNATURES = {
     "bark_forest_pack": (ci, [vp, vp, i64, ctypes.POINTER(PackInfo), vp]),
     "bark_leaf_indices_hip": (ci, [vp, ctypes.POINTER(PackInfo), vp, i64, i64, vp, vp]),
     "bark_leaf_npad": (i64, [i64]),
-    "bark_leaf_bytes_hip": (ci, [vp, ctypes.POINTER(PackInfo), vp, i64, i64, vp, vp]),
-    "bark_gram_from_leaves_hip": (ci, [vp, i64, vp, i64, i64, i64, i64, vp, vp, vp, vp, i64, i64, vp]),
+    "bark_leaf_encoding": (ci, [ctypes.POINTER(PackInfo)]),
+    "bark_leaf_words": (i64, [ctypes.POINTER(PackInfo)]),
+    "bark_leaf_codes_hip": (ci, [vp, ctypes.POINTER(PackInfo), vp, i64, i64, vp, vp]),
+    "bark_gram_from_leaves_hip": (ci, [vp, i64, vp, i64, ctypes.POINTER(PackInfo), vp, vp, vp, vp, i64, i64, vp]),
     "bark_mll_workspace_bytes": (ctypes.c_size_t, [i64, i64, i64, i64]),
     "bark_mll_batched_hip": (ci, [vp, ctypes.POINTER(PackInfo), vp, i64, i64, vp, vp, vp, vp, ci, vp, i64, vp, vp, vp,
                                   vp, vp, vp, ctypes.c_size_t, i64, ctypes.POINTER(MllTiming), vp]),

@@ -37,7 +37,7 @@ namespace bark {
 
 int launch_gram(const uint32_t *leaf1, int npad1, const uint32_t *leaf2, int npad2, int64_t B, int64_t m, int N, int M,
                 int Nout, int Mout, const double *shift, const double *scale, const double *noise, double *out, int64_t ld,
-                int64_t batch_stride, bool pad_identity, bool upper_only, bool seven_bit, hipStream_t stream);
+                int64_t batch_stride, bool pad_identity, bool upper_only, int rep, int words, hipStream_t stream);
 
 namespace {
 
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j) {
 // panel_kernel: T[j,i] = A[j,i] - sum_{k<j} U[k,j]' U[k,i]  for i > j (all column blocks), and the
 // partial diagonal tile (j+1, j+1).  1-D grid, (matrix, tile) from xcd_map.
 // ---------------------------------------------------------------------------------------------
-template <int GEN>  // 0: A tile read from HBM; 1: generated from leaf ids (ids < 128); 2: generated (ids < 256)
+template <int GEN>  // 0: A tile read from HBM; 1 + LeafRep: A generated from the leaf codes (bytes8 / bytes7 / bits)
 __global__ __launch_bounds__(THREADS, 2) void panel_kernel(Mats p, int j, int n_right, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_kernel(Mats p, int j, int n_
 #pragma unroll
             for (int v = 0; v < 4; ++v)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) miss[v][nt] += mismatched_bytes<GEN == 1>(rw[v], cw[nt]);
+                for (int nt = 0; nt < 4; ++nt) miss[v][nt] += code_count<(GEN > 0 ? GEN - 1 : 0)>(rw[v], cw[nt]);
         }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_kernel(Mats p, int j, int n_
                 const int cc = acc_col(q, nt), gj = cb * NB + cc;
                 double val;
                 if (gi < p.N && gj < p.N) {
-                    val = inv_m * (double)(p.m - (int)miss[v][nt]);
+                    val = inv_m * (double)agree_count<(GEN > 0 ? GEN - 1 : 0)>(miss[v][nt], p.m);
                     if (has_shift) val = val - sh;
                     if (has_scale) val = sc * val;
                     if (gi == gj) val = val + jitter;
@@ -811,7 +811,7 @@ Layout make_layout(int64_t N, int64_t C, int64_t m, int64_t Bc) {
     L.cpad = C > 0 ? round_up(C, NB) : 0;
     L.ncols = L.npad + L.cpad;
     L.ld = L.ncols + 16;  // +128 B: consecutive rows of a tile do not alias the same HBM channel set
-    L.W = (m + 3) / 4;
+    L.W = MAX_LEAF_WORDS;  // leaf-code planes are sized for the widest code any forest can need
     size_t o = 0;
     L.off_A = o;
     o = align256(o + (size_t)Bc * L.npad * L.ld * sizeof(double));
@@ -889,6 +889,8 @@ int set_lds_limits() {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS + debug_extra_lds())));
     BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(panel_kernel<2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS + debug_extra_lds())));
+    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(panel_kernel<3>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS + debug_extra_lds())));
     BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(panel_split_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
     BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(vtv_kernel),
@@ -931,7 +933,6 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
     }
     if (cov_out && C == 0) return fail(BARK_ERR_ARG, "cov_out without candidates");
     if ((flags & BARK_MLL_INCLUDE_SCALE) && !scale) return fail(BARK_ERR_ARG, "BARK_MLL_INCLUDE_SCALE without scale");
-    if (info->max_leaves > 256) return fail(BARK_ERR_ARG, "more than 256 leaves per tree is not supported");
     if (Bc > B) Bc = B;
     if (Bc > 65535) Bc = 65535;
     const Layout L = make_layout(N, C, m, Bc);
@@ -942,14 +943,16 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
     if (rc) return rc;
 
     hipStream_t caller = static_cast<hipStream_t>(stream_);
-    const bool seven = info->max_leaves <= 128;
+    const int rep = (int)leaf_rep(info);
+    const int words = (int)bark_leaf_words(info);
+    if (words > MAX_LEAF_WORDS) return fail(BARK_ERR_ARG, "forest needs %d leaf-code words per point (max %d)", words, MAX_LEAF_WORDS);
     const bool use_scale = (flags & BARK_MLL_INCLUDE_SCALE) != 0;
     // MLL-only sweeps generate A inside the panel kernel; only block rows 0 and 1 are materialised
     // (inputs of diag(0), solve(0), diag(1)).  With candidates the whole matrix is filled up front.
     static const bool fuse_env = getenv("BARK_NO_FUSED_GRAM") == nullptr;
     static const bool splitk_env = getenv("BARK_NO_SPLITK") == nullptr;
     const bool splitk = L.splitk && splitk_env;  // then A is materialised (the reduce kernel reads it)
-    const bool fused = fuse_env && !splitk && C == 0 && (size_t)2 * L.W * NB * sizeof(uint32_t) <= GEMM_LDS;
+    const bool fused = fuse_env && !splitk && C == 0 && (size_t)2 * words * NB * sizeof(uint32_t) <= GEMM_LDS;
     double *slabs = reinterpret_cast<double *>(static_cast<char *>(workspace) + L.off_slab);
     static const bool overlap_env = getenv("BARK_NO_DIAG_OVERLAP") == nullptr;
     const int nrb = (int)(L.npad / NB), ncb = (int)(L.ncols / NB);
@@ -973,7 +976,7 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
         p.accum = reinterpret_cast<double *>(ws + L.off_acc);
         p.nrb = nrb;
         p.ncb = ncb;
-        p.nW = (int)L.W;
+        p.nW = words;
         p.m = (int)m;
         p.N = (int)N;
         ln.leafx = reinterpret_cast<uint32_t *>(ws + L.off_leafx);
@@ -1011,19 +1014,19 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
         int r;
         if (timing) gram_marks.push_back(ev.size());
         if ((r = mark_on(s))) return r;
-        if ((r = bark_leaf_bytes_hip(packed_c, &sub, X, N, d, ln.leafx, s))) return r;
+        if ((r = bark_leaf_codes_hip(packed_c, &sub, X, N, d, ln.leafx, s))) return r;
         const int fill_rows = fused ? (int)(L.npad < 2 * NB ? L.npad : 2 * NB) : (int)L.npad;
         r = launch_gram(ln.leafx, (int)L.npad, ln.leafx, (int)L.npad, bc, m, (int)N, (int)N, fill_rows, (int)L.npad,
-                        p.shift, p.scale, p.noise, p.A, L.ld, p.bstride, true, true, seven, s);
+                        p.shift, p.scale, p.noise, p.A, L.ld, p.bstride, true, true, rep, words, s);
         if (r) return r;
         if (rhs_identity) {
             dim3 g((unsigned)((L.cpad + 255) / 256), (unsigned)L.npad, (unsigned)bc);
             hipLaunchKernelGGL(identity_rhs_kernel, g, dim3(256), 0, s, p, (int)N, (int)L.cpad);
             BARK_LAUNCH_CHECK();
         } else if (C > 0) {
-            if ((r = bark_leaf_bytes_hip(packed_c, &sub, cand, C, d, ln.leafc, s))) return r;
+            if ((r = bark_leaf_codes_hip(packed_c, &sub, cand, C, d, ln.leafc, s))) return r;
             r = launch_gram(ln.leafx, (int)L.npad, ln.leafc, (int)L.cpad, bc, m, (int)N, (int)C, (int)L.npad,
-                            (int)L.cpad, p.shift, scale + c0, nullptr, p.A + L.npad, L.ld, p.bstride, false, false, seven, s);
+                            (int)L.cpad, p.shift, scale + c0, nullptr, p.A + L.npad, L.ld, p.bstride, false, false, rep, words, s);
             if (r) return r;
         }
         dim3 g((unsigned)((L.npad + 255) / 256), (unsigned)bc);
@@ -1069,11 +1072,13 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
                 hipLaunchKernelGGL(panel_reduce_kernel, dim3((unsigned)n_tiles, (unsigned)bc), dim3(THREADS), 0, ps, p, j,
                                    n_right, n_tiles, S, slabs);
             } else if (!fused)
-                hipLaunchKernelGGL(panel_kernel<0>, pg, dim3(THREADS), pl, ps, p, j, n_right, n_right + n_diag);
-            else if (seven)
-                hipLaunchKernelGGL(panel_kernel<1>, pg, dim3(THREADS), pl, ps, p, j, n_right, n_right + n_diag);
+                hipLaunchKernelGGL(panel_kernel<0>, pg, dim3(THREADS), pl, ps, p, j, n_right, n_tiles);
+            else if (rep == REP_BITS)
+                hipLaunchKernelGGL(panel_kernel<1 + REP_BITS>, pg, dim3(THREADS), pl, ps, p, j, n_right, n_tiles);
+            else if (rep == REP_BYTES7)
+                hipLaunchKernelGGL(panel_kernel<1 + REP_BYTES7>, pg, dim3(THREADS), pl, ps, p, j, n_right, n_tiles);
             else
-                hipLaunchKernelGGL(panel_kernel<2>, pg, dim3(THREADS), pl, ps, p, j, n_right, n_right + n_diag);
+                hipLaunchKernelGGL(panel_kernel<1 + REP_BYTES8>, pg, dim3(THREADS), pl, ps, p, j, n_right, n_tiles);
             BARK_LAUNCH_CHECK();
             if ((r = mark_on(ps))) return r;
             panel_flops += 2.0 * NB * NB * (double)(j * NB) * (double)(n_right + n_diag) * (double)bc;

@@ -30,6 +30,7 @@ constexpr uint32_t CAT_FLAG = 0x40000000u;
 constexpr uint32_t FEAT_MASK = 0x3FFFFFFFu;
 
 constexpr int TILE = 128;  // Cholesky block size == MFMA tile edge per workgroup
+constexpr int MAX_LEAF_WORDS = 112;  // leaf-code dwords per point the Gram kernels can stage in LDS
 
 inline int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
 
@@ -45,6 +46,24 @@ __device__ __forceinline__ uint32_t mismatched_bytes(uint32_t a, uint32_t b) {
     else
         z = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
     return __popc(z);
+}
+
+// leaf-code encodings (include/bark_hip.h): how the Gram kernels turn two code words into a count
+enum LeafRep { REP_BYTES8 = 0, REP_BYTES7 = 1, REP_BITS = 2 };
+inline LeafRep leaf_rep(const bark_pack_info *info) {
+    if (bark_leaf_encoding(info) == BARK_LEAF_BITS) return REP_BITS;
+    return info->max_leaves <= 128 ? REP_BYTES7 : REP_BYTES8;
+}
+// per code word: number of disagreeing trees (byte encodings) or of agreeing trees (one-hot bits)
+template <int REP>
+__device__ __forceinline__ uint32_t code_count(uint32_t a, uint32_t b) {
+    if (REP == REP_BITS) return __popc(a & b);
+    return mismatched_bytes<REP == REP_BYTES7>(a, b);
+}
+// trees that agree, from the accumulated per-word counts
+template <int REP>
+__device__ __forceinline__ int agree_count(uint32_t acc, int m) {
+    return REP == REP_BITS ? (int)acc : m - (int)acc;
 }
 
 }  // namespace bark

@@ -5,16 +5,23 @@
 //
 // The reference materialises an N x M x m boolean tensor (forest.py:87) and sums it; here a
 // 64x64 output tile is produced per workgroup from two strips of byte-packed leaf ids held in
-// LDS (4 trees per dword).  A tree pair agrees iff its byte of `a ^ b` is zero, so one
-// xor + add + and + v_bcnt handles 4 trees (dense ids < 128 keep bit 7 clear, which makes
-// `x + 0x7f7f7f7f` carry-free per byte; the general form masks first).  The kernel is bound
-// by the 8*N*M bytes of fp64 output it streams to HBM: each wave store instruction writes
-// four 256-byte row segments (16 lanes x 16 B).
+// LDS.  Two encodings of a point's leaves (include/bark_hip.h, bark_leaf_encoding):
+//   one-hot bits : tree t owns L_t bits, #agreeing trees = popcount(z_i & z_j): v_and + v_bcnt per 32 bits
+//                  (a forest with ~3 leaves per tree needs 5 dwords for 50 trees);
+//   packed bytes : 4 trees per dword, a pair agrees iff its byte of `a ^ b` is zero: xor + add + and + v_bcnt
+//                  per 4 trees (dense ids < 128 keep bit 7 clear, so `x + 0x7f7f7f7f` is carry-free).
+// With the byte code the kernel is VALU-bound (compute-only build 0.52 ms vs store-only 0.42 ms for
+// 16 x 4096^2); with the bit code it is bound by the 8*N*M bytes of fp64 output it streams to HBM: each
+// wave store instruction writes four 256-byte row segments (16 lanes x 16 B).
 //
 // Bit-exactness: the reference computes `1 / m * count` => fl(fl(1/m) * count); optional
 // `scale *` and `+ (1e-6 + noise)` on the diagonal follow in the reference's order
 // (tree_gps.py:97-100).  The library is built with -ffp-contract=off so no FMA fuses them.
 #include "common.h"
+
+#ifndef BARK_GRAM_ABLATE
+#define BARK_GRAM_ABLATE 0
+#endif
 
 namespace bark {
 namespace {
@@ -37,7 +44,7 @@ struct GramArgs {
     int upper_only;    // 1: skip 64-tiles strictly below the 128-block diagonal
 };
 
-template <bool SEVEN_BIT, bool VEC2>
+template <int REP, bool VEC2>
 __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(GramArgs p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t strips[];  // rows[W][64] | cols[W][64]
     const int tid = threadIdx.x;
@@ -56,8 +63,12 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(GramArgs p) {
     __syncthreads();
 
     const int ty = tid >> 4, tx = tid & 15;
-    uint32_t miss[4][4] = {};
+    uint32_t cnt[4][4] = {};  // disagreeing trees (byte codes) / agreeing trees (bit code)
+#if BARK_GRAM_ABLATE == 1  // timing only: no compare loop
+    for (int w = 0; w < 0; ++w) {
+#else
     for (int w = 0; w < p.W; ++w) {
+#endif
         const uint4 r4 = *reinterpret_cast<const uint4 *>(rows + w * GT + ty * 4);
         const uint2 ca = *reinterpret_cast<const uint2 *>(cols + w * GT + 2 * tx);
         const uint2 cb = *reinterpret_cast<const uint2 *>(cols + w * GT + 32 + 2 * tx);
@@ -66,7 +77,7 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(GramArgs p) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) miss[a][q] += mismatched_bytes<SEVEN_BIT>(r[a], c[q]);
+            for (int q = 0; q < 4; ++q) cnt[a][q] += code_count<REP>(r[a], c[q]);
     }
 
     const double inv_m = 1.0 / (double)p.m;  // forest.py:88 `1 / nodes.shape[0]`
@@ -86,7 +97,7 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(GramArgs p) {
             const int j = col0 + (q >> 1) * 32 + 2 * tx + (q & 1);
             double val;
             if (i < p.N && j < p.M) {
-                val = inv_m * (double)(p.m - (int)miss[a][q]);  // unused byte lanes are equal (0) on both sides
+                val = inv_m * (double)agree_count<REP>(cnt[a][q], p.m);  // unused byte lanes are equal, unused bits 0
                 if (has_shift) val = val - sh;  // forest.py:111
                 if (has_scale) val = sc * val;
                 if (p.noise && i == j) val = val + jitter;
@@ -99,6 +110,9 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(GramArgs p) {
         for (int h = 0; h < 2; ++h) {
             const int j = col0 + h * 32 + 2 * tx;
             double *dst = outb + (size_t)i * p.ld + j;
+#if BARK_GRAM_ABLATE == 2  // timing only: (almost) no stores
+            if (v[2 * h] != -1.0) continue;
+#endif
             if (VEC2 && j + 1 < p.Mout) {
                 *reinterpret_cast<double2 *>(dst) = make_double2(v[2 * h], v[2 * h + 1]);
             } else {
@@ -114,14 +128,14 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(GramArgs p) {
 // shared with chol.hip (the MLL engine fills its workspace with this kernel)
 int launch_gram(const uint32_t *leaf1, int npad1, const uint32_t *leaf2, int npad2, int64_t B, int64_t m, int N, int M,
                 int Nout, int Mout, const double *shift, const double *scale, const double *noise, double *out, int64_t ld,
-                int64_t batch_stride, bool pad_identity, bool upper_only, bool seven_bit, hipStream_t stream) {
+                int64_t batch_stride, bool pad_identity, bool upper_only, int rep, int words, hipStream_t stream) {
     GramArgs p;
     p.shift = shift;
     p.leaf1 = leaf1;
     p.leaf2 = leaf2;
     p.npad1 = npad1;
     p.npad2 = npad2;
-    p.W = (int)((m + 3) / 4);
+    p.W = words;
     p.m = (int)m;
     p.N = N;
     p.M = M;
@@ -139,17 +153,20 @@ int launch_gram(const uint32_t *leaf1, int npad1, const uint32_t *leaf2, int npa
     const size_t lds = (size_t)2 * p.W * GT * sizeof(uint32_t);
     if (lds > 64 * 1024) return fail(BARK_ERR_ARG, "gram: too many trees (m=%lld)", (long long)m);
     const bool vec2 = (ld % 2 == 0) && (batch_stride % 2 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-    if (seven_bit) {
-        if (vec2)
-            hipLaunchKernelGGL((gram_kernel<true, true>), grid, dim3(GRAM_THREADS), lds, stream, p);
-        else
-            hipLaunchKernelGGL((gram_kernel<true, false>), grid, dim3(GRAM_THREADS), lds, stream, p);
-    } else {
-        if (vec2)
-            hipLaunchKernelGGL((gram_kernel<false, true>), grid, dim3(GRAM_THREADS), lds, stream, p);
-        else
-            hipLaunchKernelGGL((gram_kernel<false, false>), grid, dim3(GRAM_THREADS), lds, stream, p);
-    }
+#define BARK_GRAM_LAUNCH(R)                                                                                   \
+    do {                                                                                                      \
+        if (vec2)                                                                                             \
+            hipLaunchKernelGGL((gram_kernel<R, true>), grid, dim3(GRAM_THREADS), lds, stream, p);             \
+        else                                                                                                  \
+            hipLaunchKernelGGL((gram_kernel<R, false>), grid, dim3(GRAM_THREADS), lds, stream, p);            \
+    } while (0)
+    if (rep == REP_BITS)
+        BARK_GRAM_LAUNCH(REP_BITS);
+    else if (rep == REP_BYTES7)
+        BARK_GRAM_LAUNCH(REP_BYTES7);
+    else
+        BARK_GRAM_LAUNCH(REP_BYTES8);
+#undef BARK_GRAM_LAUNCH
     BARK_LAUNCH_CHECK();
     return BARK_OK;
 }
@@ -158,18 +175,17 @@ int launch_gram(const uint32_t *leaf1, int npad1, const uint32_t *leaf2, int npa
 
 using namespace bark;
 
-extern "C" int bark_gram_from_leaves_hip(const uint32_t *leaf1, int64_t N, const uint32_t *leaf2, int64_t M, int64_t B,
-                                         int64_t m, int64_t max_leaves, const double *shift, const double *scale,
+extern "C" int bark_gram_from_leaves_hip(const uint32_t *leaf1, int64_t N, const uint32_t *leaf2, int64_t M,
+                                         const bark_pack_info *info, const double *shift, const double *scale,
                                          const double *noise, double *out, int64_t ld, int64_t batch_stride,
                                          void *stream) {
     error_buffer()[0] = 0;
-    if (!leaf1 || !leaf2 || !out) return fail(BARK_ERR_ARG, "gram: null argument");
+    if (!leaf1 || !leaf2 || !out || !info) return fail(BARK_ERR_ARG, "gram: null argument");
+    const int64_t B = info->B, m = info->m;
     if (N < 1 || M < 1 || B < 1 || m < 1 || ld < M || N > (1 << 30) || M > (1 << 30))
         return fail(BARK_ERR_ARG, "gram: bad shape N=%lld M=%lld B=%lld m=%lld ld=%lld", (long long)N, (long long)M,
                     (long long)B, (long long)m, (long long)ld);
-    if (max_leaves < 1 || max_leaves > 256) return fail(BARK_ERR_ARG, "gram: max_leaves=%lld outside [1,256]", (long long)max_leaves);
-    // dense ids < 128 keep bit 7 clear: carry-free compare; otherwise the general zero-byte count
     return launch_gram(leaf1, (int)bark_leaf_npad(N), leaf2, (int)bark_leaf_npad(M), B, m, (int)N, (int)M, (int)N,
-                       (int)M, shift, scale, noise, out, ld, batch_stride, false, false, max_leaves <= 128,
-                       static_cast<hipStream_t>(stream));
+                       (int)M, shift, scale, noise, out, ld, batch_stride, false, false, (int)leaf_rep(info),
+                       (int)bark_leaf_words(info), static_cast<hipStream_t>(stream));
 }

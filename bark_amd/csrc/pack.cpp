@@ -59,7 +59,7 @@ struct TreeStats {
 
 // Depth-first walk from the root.  `out` (may be null) receives 4 uint32 per compact node.
 int pack_tree(const uint8_t *tree, int64_t L, const int64_t *feat_types, int64_t d, Scratch &s, uint32_t *out,
-              TreeStats *stats, int64_t b, int64_t t) {
+              TreeStats *stats, int64_t b, int64_t t, uint32_t bit_base = 0) {
     s.cidx.assign((size_t)L, -1);
     s.colour.assign((size_t)L, 0);
     s.stack_node.clear();
@@ -86,7 +86,8 @@ int pack_tree(const uint8_t *tree, int64_t L, const int64_t *feat_types, int64_t
             if (slot) {
                 slot[0] = LEAF_FLAG | (uint32_t)n_leaves;
                 slot[1] = orig;
-                slot[2] = slot[3] = (uint32_t)s.cidx[orig];
+                slot[2] = bit_base + (uint32_t)n_leaves;  // this leaf's bit in the forest's one-hot code
+                slot[3] = (uint32_t)s.cidx[orig];
             }
             ++n_leaves;
             s.colour[orig] = 2;
@@ -163,8 +164,9 @@ int bark_forest_pack_info(const void *nodes26, int64_t B, int64_t m, int64_t L, 
                     (long long)m, (long long)L, (long long)d);
     const uint8_t *base = static_cast<const uint8_t *>(nodes26);
     Scratch s;
-    int64_t stride = 1, max_leaves = 1, max_depth = 0;
-    for (int64_t b = 0; b < B; ++b)
+    int64_t stride = 1, max_leaves = 1, max_depth = 0, max_bits = 1;
+    for (int64_t b = 0; b < B; ++b) {
+        int64_t bits = 0;
         for (int64_t t = 0; t < m; ++t) {
             TreeStats st;
             int rc = pack_tree(base + ((size_t)b * m + t) * L * NODE_BYTES, L, feat_types, d, s, nullptr, &st, b, t);
@@ -172,7 +174,10 @@ int bark_forest_pack_info(const void *nodes26, int64_t B, int64_t m, int64_t L, 
             if (st.nodes > stride) stride = st.nodes;
             if (st.leaves > max_leaves) max_leaves = st.leaves;
             if (st.depth > max_depth) max_depth = st.depth;
+            bits += st.leaves;
         }
+        if (bits > max_bits) max_bits = bits;
+    }
     info->B = B;
     info->m = m;
     info->L = L;
@@ -180,6 +185,7 @@ int bark_forest_pack_info(const void *nodes26, int64_t B, int64_t m, int64_t L, 
     info->max_leaves = max_leaves;
     info->max_depth = max_depth;
     info->packed_bytes = B * m * stride * 16;
+    info->max_bits = max_bits;
     return BARK_OK;
 }
 
@@ -191,7 +197,8 @@ int bark_forest_pack(const void *nodes26, const int64_t *feat_types, int64_t d, 
     uint32_t *out = static_cast<uint32_t *>(packed);
     const int64_t B = info->B, m = info->m, L = info->L, stride = info->stride;
     Scratch s;
-    for (int64_t b = 0; b < B; ++b)
+    for (int64_t b = 0; b < B; ++b) {
+        uint32_t bit_base = 0;  // trees of a forest own consecutive bit fields
         for (int64_t t = 0; t < m; ++t) {
             uint32_t *dst = out + ((size_t)b * m + t) * stride * 4;
             // unused tail slots: self-looping leaves (never reached, but harmless if they were)
@@ -201,10 +208,13 @@ int bark_forest_pack(const void *nodes26, const int64_t *feat_types, int64_t d, 
                 dst[k * 4 + 2] = dst[k * 4 + 3] = (uint32_t)k;
             }
             TreeStats st;
-            int rc = pack_tree(base + ((size_t)b * m + t) * L * NODE_BYTES, L, feat_types, d, s, dst, &st, b, t);
+            int rc = pack_tree(base + ((size_t)b * m + t) * L * NODE_BYTES, L, feat_types, d, s, dst, &st, b, t, bit_base);
             if (rc) return rc;
             if (st.nodes > stride) return fail(BARK_ERR_ARG, "bark_forest_pack: info does not match forest");
+            bit_base += (uint32_t)st.leaves;
         }
+        if ((int64_t)bit_base > info->max_bits) return fail(BARK_ERR_ARG, "bark_forest_pack: info does not match forest");
+    }
     return BARK_OK;
 }
 

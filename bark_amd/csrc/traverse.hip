@@ -39,10 +39,14 @@ __device__ __forceinline__ uint4 walk_tree(const uint4 *__restrict__ tree, int m
 
 // MODE 0: out[b][i][t] = original node index (uint32)   — the reference's (N, m) layout per forest
 // MODE 1: out[b][w][i] = 4 dense leaf ids packed per dword — Gram kernel input, Npad points per plane
+// MODE 2: out[b][w][i] = one-hot code: bit (leaf.z) set for the leaf reached in every tree; W = words.
+//         Bit positions grow with the tree index, so a thread keeps one accumulator word and flushes
+//         it whenever the next tree's bit lands in a later word.
 template <int MODE, bool X_IN_LDS>
 __global__ __launch_bounds__(WALK_THREADS) void leaf_walk_kernel(const uint4 *__restrict__ nodes, int stride, int m,
                                                                  int max_depth, const double *__restrict__ X, int N,
-                                                                 int d, int npad, uint32_t *__restrict__ out) {
+                                                                 int d, int npad, int words,
+                                                                 uint32_t *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) double xs[];
     const int tid = threadIdx.x;
     const int i = blockIdx.x * WALK_THREADS + tid;
@@ -69,6 +73,27 @@ __global__ __launch_bounds__(WALK_THREADS) void leaf_walk_kernel(const uint4 *__
         if (!live) return;
         uint32_t *o = out + ((size_t)b * N + i) * m;
         for (int t = 0; t < m; ++t) o[t] = walk_tree<X_IN_LDS>(forest + (size_t)t * stride, max_depth, xrow).y;
+    } else if (MODE == 2) {
+        if (i >= npad) return;
+        uint32_t *o = out + (size_t)b * words * npad + i;
+        int cur = 0;
+        uint32_t accw = 0;
+        if (live) {
+            for (int t = 0; t < m; ++t) {
+                const uint32_t bit = walk_tree<X_IN_LDS>(forest + (size_t)t * stride, max_depth, xrow).z;
+                const int w = (int)(bit >> 5);
+                while (cur < w && cur < words) {  // monotone: earlier words are complete
+                    o[(size_t)cur * npad] = accw;
+                    accw = 0;
+                    ++cur;
+                }
+                accw |= 1u << (bit & 31u);
+            }
+        }
+        for (; cur < words; ++cur) {
+            o[(size_t)cur * npad] = accw;
+            accw = 0;
+        }
     } else {
         const int W = (m + 3) >> 2;
         if (i >= npad) return;
@@ -96,20 +121,21 @@ int launch_walk(const void *packed, const bark_pack_info *info, const double *X,
     if (N < 1 || d < 1 || N > (1 << 30)) return fail(BARK_ERR_ARG, "leaf walk: bad N=%lld d=%lld", (long long)N, (long long)d);
     if (info->B > 65535) return fail(BARK_ERR_ARG, "leaf walk: at most 65535 forests per call (got %lld)", (long long)info->B);
     const int64_t npad = bark_leaf_npad(N);
-    if (MODE == 1 && info->max_leaves > 256)
-        return fail(BARK_ERR_ARG, "more than 256 leaves per tree (%lld) is not supported by the byte-packed Gram path",
-                    (long long)info->max_leaves);
-    const int64_t extent = MODE == 1 ? npad : N;
+    const int words = (int)bark_leaf_words(info);
+    if (MODE != 0 && words > MAX_LEAF_WORDS)
+        return fail(BARK_ERR_ARG, "forest needs %d leaf-code words per point (max %d): too many leaves in total", words,
+                    MAX_LEAF_WORDS);
+    const int64_t extent = MODE != 0 ? npad : N;
     dim3 grid((unsigned)((extent + WALK_THREADS - 1) / WALK_THREADS), (unsigned)info->B);
     const size_t lds = (size_t)WALK_THREADS * (d | 1) * sizeof(double);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint4 *nodes = static_cast<const uint4 *>(packed);
     if (lds <= 64 * 1024) {
         hipLaunchKernelGGL((leaf_walk_kernel<MODE, true>), grid, dim3(WALK_THREADS), lds, s, nodes, (int)info->stride,
-                           (int)info->m, (int)info->max_depth, X, (int)N, (int)d, (int)npad, out);
+                           (int)info->m, (int)info->max_depth, X, (int)N, (int)d, (int)npad, words, out);
     } else {
         hipLaunchKernelGGL((leaf_walk_kernel<MODE, false>), grid, dim3(WALK_THREADS), 0, s, nodes, (int)info->stride,
-                           (int)info->m, (int)info->max_depth, X, (int)N, (int)d, (int)npad, out);
+                           (int)info->m, (int)info->max_depth, X, (int)N, (int)d, (int)npad, words, out);
     }
     BARK_LAUNCH_CHECK();
     return BARK_OK;
@@ -130,10 +156,25 @@ int bark_leaf_indices_hip(const void *packed, const bark_pack_info *info, const 
     return launch_walk<0>(packed, info, X, N, d, out, stream);
 }
 
-int bark_leaf_bytes_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
+// One-hot bits cost 2 VALU per 32 bits in the Gram kernels, packed bytes 4 (6 with ids >= 128) per 4 trees:
+// take the bitset when it is the cheaper compare, and always when a tree has more leaves than a byte holds.
+int bark_leaf_encoding(const bark_pack_info *info) {
+    if (!info) return BARK_LEAF_BYTES;
+    const int64_t wbits = (info->max_bits + 31) / 32, wbytes = (info->m + 3) / 4;
+    return (info->max_leaves > 256 || wbits < 2 * wbytes) ? BARK_LEAF_BITS : BARK_LEAF_BYTES;
+}
+
+int64_t bark_leaf_words(const bark_pack_info *info) {
+    if (!info) return 0;
+    return bark_leaf_encoding(info) == BARK_LEAF_BITS ? (info->max_bits + 31) / 32 : (info->m + 3) / 4;
+}
+
+int bark_leaf_codes_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
                         uint32_t *out, void *stream) {
     error_buffer()[0] = 0;
-    return launch_walk<1>(packed, info, X, N, d, out, stream);
+    if (!info) return fail(BARK_ERR_ARG, "leaf codes: null info");
+    return bark_leaf_encoding(info) == BARK_LEAF_BITS ? launch_walk<2>(packed, info, X, N, d, out, stream)
+                                                      : launch_walk<1>(packed, info, X, N, d, out, stream);
 }
 
 }  // extern "C"

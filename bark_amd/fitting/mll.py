@@ -107,8 +107,6 @@ def _run(forest, noise, scale, X, y, feat_types, flags, cand=None, timing=None, 
         if want_cov:
             cov = torch.empty((B, C, C), dtype=torch.float64, device=Xd.device)
     pf = PackedForest(nodes3, ft)
-    if pf.info.max_leaves > 256:
-        raise ValueError(f"trees with more than 256 leaves ({pf.info.max_leaves}) are not supported")
     held = 0 if cov is None else cov.numel() * 8
     Bc = chunk or choose_chunk(B, N, C, pf.m)
     del held

@@ -144,15 +144,16 @@ def pack_forest(nodes, feat_types) -> PackedForest:
     return PackedForest(nodes3, ft)
 
 
-def _leaf_bytes(pf: PackedForest, Xd):
+def _leaf_codes(pf: PackedForest, Xd):
+    """(B, W, Npad) uint32 leaf codes (one-hot bits or packed bytes, chosen by the library from pf.info)."""
     import torch
 
     lib = _lib.lib()
     N, d = Xd.shape
     npad = int(lib.bark_leaf_npad(N))
-    W = (pf.m + 3) // 4
+    W = int(lib.bark_leaf_words(pf.info_ref))
     out = torch.empty((pf.B, W, npad), dtype=torch.int32, device=Xd.device)
-    _lib.check(lib.bark_leaf_bytes_hip(_lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(out),
+    _lib.check(lib.bark_leaf_codes_hip(_lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(out),
                                        _lib.stream_ptr()))
     return out
 
@@ -188,17 +189,15 @@ def _gram(nodes3, x1, x2, feat_types, *, shift=None, scale=None, noise=None):
         X2, _ = _points(x2, ft.shape[0])
         _check_categorical(X2, ft)
     pf = PackedForest(nodes3, ft)
-    if pf.info.max_leaves > 256:
-        raise ValueError(f"trees with more than 256 leaves ({pf.info.max_leaves}) are not supported")
-    l1 = _leaf_bytes(pf, X1)
-    l2 = l1 if same else _leaf_bytes(pf, X2)
+    l1 = _leaf_codes(pf, X1)
+    l2 = l1 if same else _leaf_codes(pf, X2)
     N, M = X1.shape[0], X2.shape[0]
     out = torch.empty((pf.B, N, M), dtype=torch.float64, device=X1.device)
     dev = lambda v: None if v is None else _lib.to_device(np.ascontiguousarray(v, dtype=np.float64))  # noqa: E731
     sh, sc, no = dev(shift), dev(scale), dev(noise)
     _lib.check(_lib.lib().bark_gram_from_leaves_hip(
-        _lib.ptr(l1), N, _lib.ptr(l2), M, pf.B, pf.m, int(pf.info.max_leaves), _lib.ptr(sh), _lib.ptr(sc),
-        _lib.ptr(no), _lib.ptr(out), M, N * M, _lib.stream_ptr()))
+        _lib.ptr(l1), N, _lib.ptr(l2), M, pf.info_ref, _lib.ptr(sh), _lib.ptr(sc), _lib.ptr(no), _lib.ptr(out), M,
+        N * M, _lib.stream_ptr()))
     return out, t1
 
 

@@ -147,24 +147,26 @@ def main():
     gram_probe = None
     if rank == 0:
         Bg = min(16, B)
-        leaves = torch.empty((Bg, (m + 3) // 4, int(lib.bark_leaf_npad(N))), dtype=torch.int32, device=Xd.device)
-        Kg = torch.empty((Bg, N, N), dtype=torch.float64, device=Xd.device)
         sub = _lib.PackInfo.from_buffer_copy(pf.info)
         sub.B = Bg
+        leaves = torch.empty((Bg, int(lib.bark_leaf_words(ctypes.byref(sub))), int(lib.bark_leaf_npad(N))),
+                             dtype=torch.int32, device=Xd.device)
+        Kg = torch.empty((Bg, N, N), dtype=torch.float64, device=Xd.device)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for it in range(3):
             if it == 1:
                 e0.record()
-            _lib.check(lib.bark_leaf_bytes_hip(_lib.ptr(pf.packed), ctypes.byref(sub), _lib.ptr(Xd), N, d,
+            _lib.check(lib.bark_leaf_codes_hip(_lib.ptr(pf.packed), ctypes.byref(sub), _lib.ptr(Xd), N, d,
                                                _lib.ptr(leaves), stream))
-            _lib.check(lib.bark_gram_from_leaves_hip(_lib.ptr(leaves), N, _lib.ptr(leaves), N, Bg, m,
-                                                     int(pf.info.max_leaves), None, None, None, _lib.ptr(Kg), N, N * N,
-                                                     stream))
+            _lib.check(lib.bark_gram_from_leaves_hip(_lib.ptr(leaves), N, _lib.ptr(leaves), N, ctypes.byref(sub), None,
+                                                     None, None, _lib.ptr(Kg), N, N * N, stream))
         e1.record()
         torch.cuda.synchronize()
         g_ms = e0.elapsed_time(e1) / 2
         g_bytes = Bg * (8.0 * N * N + 4.0 * m * 2 * N)  # SURVEY §8d bytes_gram per matrix
         gram_probe = {"bound": "hbm", "forests": Bg, "algorithmic_bytes": g_bytes, "ms": g_ms,
+                      "leaf_code": "one-hot bits" if lib.bark_leaf_encoding(ctypes.byref(sub)) == 1 else "packed bytes",
+                      "leaf_code_words": int(lib.bark_leaf_words(ctypes.byref(sub))),
                       "achieved_GBs": g_bytes / (g_ms * 1e-3) / 1e9, "peak_GBs": HBM_PEAK_GBS,
                       "frac": g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         del Kg, leaves

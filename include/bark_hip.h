@@ -58,7 +58,8 @@ const char *bark_last_error(void);
  * depth-first order (root = slot 0), containing only the nodes reachable from the root.
  *   node.w0  internal: feature_idx | (is_categorical << 30);   leaf: 0x80000000 | dense_leaf_id
  *   node.w1  internal: float32 threshold bits, or the uint32 category bitmask;  leaf: original node index
- *   node.w2/w3  compact index of left/right child
+ *   node.w2/w3  internal: compact index of left/right child;  leaf: w2 = position of the leaf's bit in the
+ *               forest's one-hot code (trees own consecutive bit fields, one bit per reachable leaf)
  * `feat_types` is the reference's int64 array (0 = Cat, 1 = Int, 2 = Cont; forest.py:22-25).
  * ------------------------------------------------------------------------------------- */
 typedef struct {
@@ -67,6 +68,7 @@ typedef struct {
     int64_t max_leaves;   /* max number of reachable leaves in any tree (dense ids < max_leaves) */
     int64_t max_depth;    /* longest root-to-leaf walk (edges) */
     int64_t packed_bytes; /* B*m*stride*16 */
+    int64_t max_bits;     /* max over forests of sum_t (#reachable leaves of tree t): width of the one-hot code */
 } bark_pack_info;
 
 /* Pass 1: validate + measure.  Fills *info. */
@@ -84,11 +86,19 @@ int bark_forest_pack(const void *nodes26, const int64_t *feat_types, int64_t d, 
 int bark_leaf_indices_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
                           uint32_t *out, void *stream);
 
-/* Byte-packed dense leaf ids used by the Gram kernels: out is (B, W, Npad) uint32 with
- * W = ceil(m/4) (4 trees per dword, unused byte lanes = 0) and Npad = bark_leaf_npad(N).
- * Requires info->max_leaves <= 256. */
+/* Leaf codes consumed by the Gram kernels: out is (B, W, Npad) uint32, W = bark_leaf_words(info),
+ * Npad = bark_leaf_npad(N), point index fastest.  Two encodings, chosen from `info` alone
+ * (bark_leaf_encoding): 
+ *   BARK_LEAF_BITS  one-hot: tree t owns L_t consecutive bits (L_t = its reachable leaves), a point sets the
+ *                   bit of the leaf it reaches in every tree; then  #agreeing trees = popcount(z_i & z_j)
+ *                   (2 VALU per 32 bits).  Chosen when max_bits < 64 * ceil(m/4), and always for trees with
+ *                   more than 256 leaves.
+ *   BARK_LEAF_BYTES 4 dense 8-bit leaf ids per dword; a tree pair agrees iff its byte of z_i ^ z_j is zero. */
+enum { BARK_LEAF_BYTES = 0, BARK_LEAF_BITS = 1 };
 int64_t bark_leaf_npad(int64_t N);
-int bark_leaf_bytes_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
+int bark_leaf_encoding(const bark_pack_info *info);
+int64_t bark_leaf_words(const bark_pack_info *info);
+int bark_leaf_codes_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
                         uint32_t *out, void *stream);
 
 /* ---------------------------------------------------------------------------------------
@@ -99,13 +109,11 @@ int bark_leaf_bytes_hip(const void *packed, const bark_pack_info *info, const do
  *   * scale[b]            (forest.py:111 `* scale`; tree_gps.py:97; bark_sampler.py:153)
  *   + (1e-6 + noise[b])   on the diagonal (tree_gps.py:100, mcmc_record_mll.py:67)
  * each rounded separately, as numpy does.  shift / scale / noise may be NULL (skipped).
- * leaf1/leaf2 come from bark_leaf_bytes_hip for x1 / x2 (pass the same pointer when x1 is x2);
- * max_leaves is bark_pack_info.max_leaves of the forest that produced them (<= 128 selects the
- * carry-free 7-bit compare).  out is (B, N, ld) float64, row stride `ld` >= M, batch stride
- * `batch_stride` elements.
+ * leaf1/leaf2 come from bark_leaf_codes_hip for x1 / x2 with the same `info` (pass the same pointer when
+ * x1 is x2).  out is (B, N, ld) float64, row stride `ld` >= M, batch stride `batch_stride` elements.
  * ------------------------------------------------------------------------------------- */
-int bark_gram_from_leaves_hip(const uint32_t *leaf1, int64_t N, const uint32_t *leaf2, int64_t M, int64_t B,
-                              int64_t m, int64_t max_leaves, const double *shift, const double *scale,
+int bark_gram_from_leaves_hip(const uint32_t *leaf1, int64_t N, const uint32_t *leaf2, int64_t M,
+                              const bark_pack_info *info, const double *shift, const double *scale,
                               const double *noise, double *out, int64_t ld, int64_t batch_stride, void *stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -186,11 +186,19 @@ def test_deep_trees_and_many_leaves(B):
     wide = B.syn.full_binary_forest(5, 6, 8, rng, node_limit=512)  # 256 leaves / tree: 8-bit ids, general compare
     assert np.array_equal(B.bf.pass_through_forest(wide, X, ft), B.orc.pass_through_forest(wide, X, ft))
     assert np.array_equal(B.bf.forest_gram_matrix(wide, X, X, ft), B.orc.forest_gram_matrix(wide, X, X, ft))
-    too_wide = B.syn.full_binary_forest(1, 6, 9, rng, node_limit=1024)  # 512 leaves: refused, not wrong
-    with pytest.raises(ValueError, match="256 leaves"):
-        B.bf.forest_gram_matrix(too_wide, X, X, ft)
-    # leaf indices themselves have no such limit
-    assert np.array_equal(B.bf.pass_through_forest(too_wide, X, ft), B.orc.pass_through_forest(too_wide, X, ft))
+    # 512 leaves per tree do not fit a byte: the one-hot code takes over (2 trees x 512 bits = 32 words)
+    huge = B.syn.full_binary_forest(2, 6, 9, rng, node_limit=1024)
+    assert np.array_equal(B.bf.pass_through_forest(huge, X, ft), B.orc.pass_through_forest(huge, X, ft))
+    assert np.array_equal(B.bf.forest_gram_matrix(huge, X, X, ft), B.orc.forest_gram_matrix(huge, X, X, ft))
+    # byte code with ids >= 128 (50 trees x 256 leaves would need 400 words as bits)
+    wide50 = B.syn.full_binary_forest(50, 6, 8, rng, node_limit=512)
+    assert np.array_equal(B.bf.forest_gram_matrix(wide50, X, X, ft), B.orc.forest_gram_matrix(wide50, X, X, ft))
+    deep50 = B.syn.full_binary_forest(50, 6, 5, rng)  # 32 leaves: byte code with ids < 128
+    y = rng.standard_normal((300, 1))
+    for forest in (deep50, wide50):
+        got = B.fit.batched_mll(forest[None], [0.1], [1.0], X, y, ft, include_scale=True, include_2pi=True)
+        want = B.orc.batched_mll(forest[None], [0.1], [1.0], X, y, ft, include_scale=True, include_2pi=True)
+        assert np.allclose(got, want, rtol=MLL_RTOL, atol=MLL_ATOL)
 
 
 def test_wide_feature_matrix_walks_from_global_memory(B):

@@ -55,7 +55,7 @@ def walk_packed(packed_tree, x, max_depth):
             left = x[f] <= float(np.uint32(n[1]).view(np.float32))
         n = packed_tree[int(n[2] if left else n[3])]
     assert n[0] & LEAF
-    return int(n[1]), int(n[0] & 0xFF)
+    return int(n[1]), int(n[0] & 0xFF), int(n[2])
 
 
 @pytest.mark.parametrize("name", ["g1_kat_tree", "g3_prior_mixed_n64", "g5_boundaries", "g7_tree_function"])
@@ -69,14 +69,24 @@ def test_packer_wire_format_reproduces_reference_leaves(name):
     leaves = g["leaves"].reshape(nodes3.shape[0], X.shape[0], nodes3.shape[1])
     info, packed = host_pack(nodes3, ft)
     assert info.stride <= nodes3.shape[2] and info.max_leaves <= (nodes3.shape[2] + 1) // 2 + 1
+    codes = np.zeros((nodes3.shape[0], X.shape[0], (info.max_bits + 31) // 32), dtype=np.uint32)
     for b in range(nodes3.shape[0]):
         for t in range(nodes3.shape[1]):
             dense_of = {}
             for i in range(X.shape[0]):
-                orig, dense = walk_packed(packed[b, t], X[i], info.max_depth)
+                orig, dense, bit = walk_packed(packed[b, t], X[i], info.max_depth)
                 assert orig == leaves[b, i, t]
                 assert dense_of.setdefault(orig, dense) == dense and dense < info.max_leaves
+                codes[b, i, bit // 32] |= np.uint32(1) << np.uint32(bit % 32)
+                assert bit < info.max_bits
             assert len(set(dense_of.values())) == len(dense_of)  # dense ids are a bijection of reached leaves
+    # one-hot code: every point sets exactly one bit per tree, and popcount(z_i & z_j) counts agreeing trees
+    pop = np.vectorize(lambda v: bin(int(v)).count("1"))
+    for b in range(nodes3.shape[0]):
+        assert (pop(codes[b]).sum(axis=1) == nodes3.shape[1]).all()
+        agree = (leaves[b][:, None, :] == leaves[b][None, :, :]).sum(-1)
+        both = pop(codes[b][:, None, :] & codes[b][None, :, :]).sum(-1)
+        assert np.array_equal(agree, both)
 
 
 def test_packer_statistics_match_active_nodes():
@@ -88,6 +98,14 @@ def test_packer_statistics_match_active_nodes():
     leaves = ((F["active"] == 1) & (F["is_leaf"] == 1)).sum(-1)
     assert info.max_leaves == leaves.max()
     assert info.max_depth == F["depth"][F["active"] == 1].max()
+    assert info.max_bits == leaves.sum(-1).max()
+    lib = _lib.lib()
+    assert lib.bark_leaf_encoding(ctypes.byref(info)) == 1  # ~3 leaves / tree: the one-hot code is the cheaper one
+    assert lib.bark_leaf_words(ctypes.byref(info)) == (info.max_bits + 31) // 32
+    deep = synthetic.full_binary_forest(50, 8, 5, np.random.default_rng(0))[None]  # 32 leaves / tree
+    dinfo, _ = host_pack(deep, np.full(8, 2))
+    assert dinfo.max_bits == 1600 and lib.bark_leaf_encoding(ctypes.byref(dinfo)) == 0
+    assert lib.bark_leaf_words(ctypes.byref(dinfo)) == 13
 
 
 def _tree(rows, L=8):
