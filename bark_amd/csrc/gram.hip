@@ -12,7 +12,7 @@
 //                  per 4 trees (dense ids < 128 keep bit 7 clear, so `x + 0x7f7f7f7f` is carry-free).
 // With the byte code the kernel is VALU-bound (compute-only build 0.52 ms vs store-only 0.42 ms for
 // 16 x 4096^2); with the bit code it is bound by the 8*N*M bytes of fp64 output it streams to HBM: each
-// wave store instruction writes four 256-byte row segments (16 lanes x 16 B).
+// wave store instruction writes two full 512-byte row segments (32 lanes x 16 B).
 //
 // Bit-exactness: the reference computes `1 / m * count` => fl(fl(1/m) * count); optional
 // `scale *` and `+ (1e-6 + noise)` on the diagonal follow in the reference's order
@@ -62,22 +62,25 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(GramArgs p) {
     }
     __syncthreads();
 
-    const int ty = tid >> 4, tx = tid & 15;
-    uint32_t cnt[4][4] = {};  // disagreeing trees (byte codes) / agreeing trees (bit code)
+    // thread -> 8 rows x 2 columns: wave w owns rows 16w..16w+15, half-wave h rows 8h..8h+7 of those, lane pair
+    // column 2*cx.  One store instruction then writes two full 512-byte row segments (32 lanes x 16 B each).
+    const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, cx = lane & 31;
+    const int rloc = wave * 16 + half * 8;
+    uint32_t cnt[8][2] = {};  // disagreeing trees (byte codes) / agreeing trees (bit code)
 #if BARK_GRAM_ABLATE == 1  // timing only: no compare loop
     for (int w = 0; w < 0; ++w) {
 #else
     for (int w = 0; w < p.W; ++w) {
 #endif
-        const uint4 r4 = *reinterpret_cast<const uint4 *>(rows + w * GT + ty * 4);
-        const uint2 ca = *reinterpret_cast<const uint2 *>(cols + w * GT + 2 * tx);
-        const uint2 cb = *reinterpret_cast<const uint2 *>(cols + w * GT + 32 + 2 * tx);
-        const uint32_t r[4] = {r4.x, r4.y, r4.z, r4.w};
-        const uint32_t c[4] = {ca.x, ca.y, cb.x, cb.y};
+        const uint4 ra = *reinterpret_cast<const uint4 *>(rows + w * GT + rloc);
+        const uint4 rb = *reinterpret_cast<const uint4 *>(rows + w * GT + rloc + 4);
+        const uint2 cc = *reinterpret_cast<const uint2 *>(cols + w * GT + 2 * cx);
+        const uint32_t r[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) cnt[a][q] += code_count<REP>(r[a], c[q]);
+        for (int a = 0; a < 8; ++a) {
+            cnt[a][0] += code_count<REP>(r[a], cc.x);
+            cnt[a][1] += code_count<REP>(r[a], cc.y);
+        }
     }
 
     const double inv_m = 1.0 / (double)p.m;  // forest.py:88 `1 / nodes.shape[0]`
@@ -86,15 +89,16 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(GramArgs p) {
     const double sc = has_scale ? p.scale[b] : 1.0;
     const double jitter = p.noise ? (1e-6 + p.noise[b]) : 0.0;  // tree_gps.py:100
     double *outb = p.out + (size_t)b * p.batch_stride;
+    const int j0 = col0 + 2 * cx;
 
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int i = row0 + ty * 4 + a;
+    for (int a = 0; a < 8; ++a) {
+        const int i = row0 + rloc + a;
         if (i >= p.Nout) continue;
-        double v[4];
+        double v[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = col0 + (q >> 1) * 32 + 2 * tx + (q & 1);
+        for (int q = 0; q < 2; ++q) {
+            const int j = j0 + q;
             double val;
             if (i < p.N && j < p.M) {
                 val = inv_m * (double)agree_count<REP>(cnt[a][q], p.m);  // unused byte lanes are equal, unused bits 0
@@ -106,19 +110,15 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(GramArgs p) {
             }
             v[q] = val;
         }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int j = col0 + h * 32 + 2 * tx;
-            double *dst = outb + (size_t)i * p.ld + j;
+        double *dst = outb + (size_t)i * p.ld + j0;
 #if BARK_GRAM_ABLATE == 2  // timing only: (almost) no stores
-            if (v[2 * h] != -1.0) continue;
+        if (v[0] != -1.0) continue;
 #endif
-            if (VEC2 && j + 1 < p.Mout) {
-                *reinterpret_cast<double2 *>(dst) = make_double2(v[2 * h], v[2 * h + 1]);
-            } else {
-                if (j < p.Mout) dst[0] = v[2 * h];
-                if (j + 1 < p.Mout) dst[1] = v[2 * h + 1];
-            }
+        if (VEC2 && j0 + 1 < p.Mout) {
+            *reinterpret_cast<double2 *>(dst) = make_double2(v[0], v[1]);
+        } else {
+            if (j0 < p.Mout) dst[0] = v[0];
+            if (j0 + 1 < p.Mout) dst[1] = v[1];
         }
     }
 }

@@ -153,7 +153,8 @@ def main():
                              dtype=torch.int32, device=Xd.device)
         Kg = torch.empty((Bg, N, N), dtype=torch.float64, device=Xd.device)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for it in range(3):
+        reps = 8
+        for it in range(reps + 1):
             if it == 1:
                 e0.record()
             _lib.check(lib.bark_leaf_codes_hip(_lib.ptr(pf.packed), ctypes.byref(sub), _lib.ptr(Xd), N, d,
@@ -162,7 +163,7 @@ def main():
                                                      None, None, _lib.ptr(Kg), N, N * N, stream))
         e1.record()
         torch.cuda.synchronize()
-        g_ms = e0.elapsed_time(e1) / 2
+        g_ms = e0.elapsed_time(e1) / reps
         g_bytes = Bg * (8.0 * N * N + 4.0 * m * 2 * N)  # SURVEY §8d bytes_gram per matrix
         gram_probe = {"bound": "hbm", "forests": Bg, "algorithmic_bytes": g_bytes, "ms": g_ms,
                       "leaf_code": "one-hot bits" if lib.bark_leaf_encoding(ctypes.byref(sub)) == 1 else "packed bytes",
