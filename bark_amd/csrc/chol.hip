@@ -219,19 +219,18 @@ __device__ __forceinline__ void gemm_kmajor(f64x4 (&acc)[4][4], const double *__
 // products each instead of 32, perfectly balanced.
 
 // acc[rt(mt)][nt] += sum_k W[k][r] T[k][c] with W (A operand, row stride 128) upper triangular: k-tiles above
-// a row tile are skipped.  Same staging/pipeline as gemm_kmajor (K = 128).
+// a row tile are skipped.  Same LDS-DMA staging/pipeline as gemm_kmajor_dma (K = 128).
 __device__ __forceinline__ void gemm_upper_tri(f64x4 (&acc)[4][4], const int (&rt)[4], const double *__restrict__ W,
                                                const double *__restrict__ T, long ldt, double *lds, int tid,
                                                const Lane &q) {
     constexpr int nk = NB / BK;
-    const int lrow = tid >> 6, lcol = (tid & 63) * 2;
-    StageRegs regs;
-    stage_load(regs, W, NB, T, ldt, 0, lrow, lcol);
-    stage_store(regs, lds, lrow, lcol);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    stage_dma(W, NB, T, ldt, 0, lds, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) stage_load(regs, W, NB, T, ldt, kt + 1, lrow, lcol);
+        if (kt + 1 < nk) stage_dma(W, NB, T, ldt, kt + 1, lds + ((kt + 1) & 1) * STAGE, wave, lane);
         const double *As = lds + (kt & 1) * STAGE;
         const double *Bs = As + BK * LDS_LD;
 #pragma unroll
@@ -249,7 +248,7 @@ __device__ __forceinline__ void gemm_upper_tri(f64x4 (&acc)[4][4], const int (&r
                 }
             }
         }
-        if (kt + 1 < nk) stage_store(regs, lds + ((kt + 1) & 1) * STAGE, lrow, lcol);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 }

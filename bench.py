@@ -178,6 +178,7 @@ def main():
     per_step = {k: v / steps for k, v in tsum.items()}
     chol_flops = B * N**3 / 3.0  # algorithmic flops of one launch sequence (SURVEY §8d flops_chol x B)
     chol_tflops = chol_flops / (per_step["chol_ms"] * 1e-3) / 1e12
+    traffic = hbm_traffic_from_profile()
     result = {
         "metric": "forest-Gram + Cholesky MLL evals/sec at N=4096, 50 trees",
         "value": value,
@@ -205,7 +206,9 @@ def main():
             "peak": F64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": chol_tflops / F64_MFMA_PEAK_TFLOPS,
-            "traffic": hbm_traffic_from_profile(),
+            "traffic": traffic["bytes_per_step"] if traffic else None,
+            "traffic_unit": "bytes of HBM traffic per step (one Cholesky launch sequence, 256 evals)",
+            "traffic_source": traffic["source"] if traffic else None,
             "algorithmic_flops_per_step": chol_flops,
             "ms_per_step": {k: round(v, 3) for k, v in per_step.items()},
             "panel_kernel": {
