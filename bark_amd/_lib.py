@@ -57,6 +57,8 @@ SIGNATURES = {
     "bark_quadform_hip": (ci, [vp, vp, i64, vp, vp]),
     "bark_lowrank_workspace_bytes": (ctypes.c_size_t, [i64, i64]),
     "bark_lowrank_update_hip": (ci, [vp, i64, vp, i64, ci, ci, vp, vp, vp, ctypes.c_size_t, vp]),
+    "bark_lowrank_swap_eval_hip": (ci, [vp, i64, vp, i64, i64, vp, vp, vp, ctypes.c_size_t, vp]),
+    "bark_lowrank_swap_apply_hip": (ci, [vp, i64, i64, vp, vp, vp]),
 }
 
 _lib = None

@@ -55,11 +55,14 @@ __global__ __launch_bounds__(LR_THREADS) void skinny_kernel(const double *__rest
     }
 }
 
-// One workgroup: G = U'Y (r x r), den = mul I + G, Gauss-Jordan with partial pivoting -> den^-1 and
-// log|det den|; then M = Y den^-1 (N x r).  `logabsdet` may be null, `M` may be null (det only).
+// One workgroup: G = U'Y (r x r), den = C + G with C = diag(+-1) (the first r_neg columns carry -1: leaf
+// vectors being removed), Gauss-Jordan with partial pivoting -> den^-1 and log|det den|; then
+// M = Y den^-1 (N x r).  With `y`: also v = Y'y and dquad = v' den^-1 v (the change of y'K^-1 y).
+// `logabsdet`, `M`, `y`/`dquad` may be null.
 __global__ __launch_bounds__(LR_THREADS) void small_kernel(const double *__restrict__ U, const double *__restrict__ Y,
-                                                           int N, int r, double mul, double *__restrict__ M,
-                                                           double *__restrict__ logabsdet, int *__restrict__ singular) {
+                                                           int N, int r, int r_neg, double *__restrict__ M,
+                                                           double *__restrict__ logabsdet, int *__restrict__ singular,
+                                                           const double *__restrict__ y, double *__restrict__ dquad) {
     __shared__ double aug[LR_MAX][2 * LR_MAX + 1];  // [den | I]
     __shared__ int piv_row;
     const int tid = threadIdx.x;
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(LR_THREADS) void small_kernel(const double *__restr
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) g += __shfl_xor(g, off);
         if ((tid & 63) == 0) {
-            aug[a][bcol] = g + (a == bcol ? mul : 0.0);
+            aug[a][bcol] = g + (a == bcol ? (a < r_neg ? -1.0 : 1.0) : 0.0);
             aug[a][r + bcol] = (a == bcol) ? 1.0 : 0.0;
         }
     }
@@ -113,6 +116,23 @@ __global__ __launch_bounds__(LR_THREADS) void small_kernel(const double *__restr
         __syncthreads();
     }
     if (tid == 0 && logabsdet) *logabsdet = logsum;
+    if (y && dquad) {  // v = Y'y (wave per column), dquad = v' den^-1 v
+        __shared__ double vsh[LR_MAX];
+        for (int a = tid >> 6; a < r; a += LR_THREADS / 64) {
+            double s = 0.0;
+            for (int k = tid & 63; k < N; k += 64) s = fma(Y[(size_t)k * r + a], y[k], s);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+            if ((tid & 63) == 0) vsh[a] = s;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double q = 0.0;
+            for (int a = 0; a < r; ++a)
+                for (int b2 = 0; b2 < r; ++b2) q = fma(vsh[a] * aug[a][r + b2], vsh[b2], q);
+            *dquad = q;
+        }
+    }
     if (M)
         for (int e = tid; e < N * r; e += LR_THREADS) {
             const int i = e / r, c = e - i * r;
@@ -188,7 +208,7 @@ int bark_lowrank_update_hip(const double *K_inv, int64_t N, const double *U, int
     double *R = Y + N * r;
     double *M = R + N * r;
     int *flag = reinterpret_cast<int *>(M + N * r);
-    const double mul = subtract ? -1.0 : 1.0;
+    const int r_neg = subtract ? (int)r : 0;
     const unsigned rows_per_block = LR_THREADS / 64;
     const dim3 g1((unsigned)((N + rows_per_block - 1) / rows_per_block));
     const size_t lds1 = (size_t)64 * r * sizeof(double);
@@ -201,8 +221,8 @@ int bark_lowrank_update_hip(const double *K_inv, int64_t N, const double *U, int
         Rp = R;
     }
     BARK_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), stream));
-    hipLaunchKernelGGL(small_kernel, dim3(1), dim3(LR_THREADS), 0, stream, U, Y, (int)N, (int)r, mul,
-                       K_out ? M : nullptr, logabsdet_out, flag);
+    hipLaunchKernelGGL(small_kernel, dim3(1), dim3(LR_THREADS), 0, stream, U, Y, (int)N, (int)r, r_neg,
+                       K_out ? M : nullptr, logabsdet_out, flag, (const double *)nullptr, (double *)nullptr);
     BARK_LAUNCH_CHECK();
     if (K_out) {
         const dim3 g3((unsigned)((N + 63) / 64), (unsigned)((N + 63) / 64));
@@ -210,6 +230,54 @@ int bark_lowrank_update_hip(const double *K_inv, int64_t N, const double *U, int
                            M, Rp, (int)N, (int)r, K_out);
         BARK_LAUNCH_CHECK();
     }
+    return BARK_OK;
+}
+
+// ---- fused tree swap (the per-tree step of the sampler, bark_sampler.py:233-257) -----------------
+// The reference evaluates a proposal by  subtract(U_old) -> add(U_new) -> mll  (2 Woodbury + 2 determinant
+// updates + one quadratic form, ~9 passes over the N x N inverse) before it knows whether to accept.
+// With U = [U_old U_new], C = diag(-I, +I), Y = K^-1 U, G = U'Y, v = Y'y:
+//     log|K'| = log|K| + log|det(C + G)|,     y'K'^-1 y = y'K^-1 y - v'(C + G)^-1 v,
+//     K'^-1   = K^-1 - Y (C + G)^-1 Y'        (only needed when the proposal is accepted).
+// bark_lowrank_swap_eval_hip makes ONE pass over K^-1 and leaves Y, M = Y (C+G)^-1 in the workspace;
+// bark_lowrank_swap_apply_hip performs the rank-(r_old + r_new) update from them (read + write pass).
+// K_inv must be symmetric (it is an SPD inverse).  scalars_out (device): {dquad, log|det(C+G)|}.
+int bark_lowrank_swap_eval_hip(const double *K_inv, int64_t N, const double *U, int64_t r_old, int64_t r_new,
+                               const double *y, double *scalars_out, void *workspace, size_t workspace_bytes,
+                               void *stream_) {
+    error_buffer()[0] = 0;
+    const int64_t r = r_old + r_new;
+    if (!K_inv || !U || !y || !scalars_out || !workspace || N < 1 || r_old < 0 || r_new < 0 || r < 1 || N > (1 << 24))
+        return fail(BARK_ERR_ARG, "bark_lowrank_swap_eval_hip: bad argument");
+    if (r > LR_MAX) return fail(BARK_ERR_ARG, "tree swap supports r_old + r_new <= %d (got %lld)", LR_MAX, (long long)r);
+    if (workspace_bytes < bark_lowrank_workspace_bytes(N, r)) return fail(BARK_ERR_WORKSPACE, "low-rank workspace too small");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    double *Y = static_cast<double *>(workspace);
+    double *M = Y + 2 * N * r;
+    int *flag = reinterpret_cast<int *>(M + N * r);
+    const unsigned rows_per_block = LR_THREADS / 64;
+    const dim3 g1((unsigned)((N + rows_per_block - 1) / rows_per_block));
+    launch_skinny<0>(g1, (size_t)64 * r * sizeof(double), stream, K_inv, U, (int)N, (int)r, Y);
+    BARK_LAUNCH_CHECK();
+    BARK_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), stream));
+    hipLaunchKernelGGL(small_kernel, dim3(1), dim3(LR_THREADS), 0, stream, U, Y, (int)N, (int)r, (int)r_old, M,
+                       scalars_out + 1, flag, y, scalars_out);
+    BARK_LAUNCH_CHECK();
+    return BARK_OK;
+}
+
+int bark_lowrank_swap_apply_hip(const double *K_inv, int64_t N, int64_t r, const void *workspace, double *K_out,
+                                void *stream_) {
+    error_buffer()[0] = 0;
+    if (!K_inv || !K_out || !workspace || N < 1 || r < 1 || r > LR_MAX)
+        return fail(BARK_ERR_ARG, "bark_lowrank_swap_apply_hip: bad argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const double *Y = static_cast<const double *>(workspace);
+    const double *M = Y + 2 * N * r;
+    const dim3 g3((unsigned)((N + 63) / 64), (unsigned)((N + 63) / 64));
+    hipLaunchKernelGGL(rank_update_kernel, g3, dim3(LR_THREADS), (size_t)2 * 64 * r * sizeof(double), stream, K_inv, M,
+                       Y, (int)N, (int)r, K_out);
+    BARK_LAUNCH_CHECK();
     return BARK_OK;
 }
 

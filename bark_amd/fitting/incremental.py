@@ -1,0 +1,101 @@
+"""Device-resident state for the sampler's per-tree Metropolis step (reference:
+src/bark/fitting/bark_sampler.py:217-264, `_step_bark_sampler`).
+
+The reference keeps `cur_K_inv`, `cur_K_logdet`, `cur_mll` per chain and, for every tree proposal, chains
+
+    low_rank_inv_update(subtract old leaf vectors) -> low_rank_det_update -> low_rank_inv_update(add new)
+    -> low_rank_det_update -> mll                                     (bark_sampler.py:242-257)
+
+i.e. about nine passes over the N x N inverse before the accept/reject.  `ChainState.propose` gets the same
+`new_mll` from ONE pass (Y = K_inv [U_old U_new]) plus (r_old + r_new)^2 algebra, and `accept` rewrites
+K_inv only for accepted proposals (one read + write pass).  The host keeps the control flow (proposal,
+RNG, accept/reject), exactly as in the reference; only the linear algebra lives on the GPU.
+This is an additive API (the drop-in functions of `quick_inverse` remain available)."""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .. import _lib
+from ..forest import _is_torch, get_leaf_vectors
+from .mll import batched_kernel_inverse
+
+
+def _dev64(a):
+    import torch
+
+    t = _lib.to_device(a.detach() if _is_torch(a) else np.asarray(a, dtype=np.float64))
+    return t.to(torch.float64).contiguous()
+
+
+class ChainState:
+    """K_inv (N, N), log|K|, y'K_inv y and the targets y of one chain, resident in HBM."""
+
+    def __init__(self, K_inv, K_logdet, y):
+        import torch
+
+        self.K_inv = _dev64(K_inv)
+        self.y = _dev64(y).reshape(-1).contiguous()
+        self.N = self.y.shape[0]
+        if self.K_inv.shape != (self.N, self.N):
+            raise ValueError(f"K_inv is {tuple(self.K_inv.shape)}, y has {self.N} rows")
+        self.logdet = float(K_logdet)
+        q = torch.empty(1, dtype=torch.float64, device=self.K_inv.device)
+        _lib.check(_lib.lib().bark_quadform_hip(_lib.ptr(self.K_inv), _lib.ptr(self.y), self.N, _lib.ptr(q),
+                                                _lib.stream_ptr()))
+        self.quad = float(q.item())
+        self._pending = None
+
+    @classmethod
+    def from_forest(cls, forest, noise, scale, X, y, feat_types):
+        """Initial state of a chain: bark_sampler.py:153-162 (scale * K + (1e-6 + noise) I, inverse, logdet)."""
+        nodes = np.asarray(forest)
+        K_inv, _, logdet = batched_kernel_inverse(nodes[None], [noise], [scale], X, y, feat_types, no_null=False,
+                                                  return_device=True)
+        return cls(K_inv[0], float(logdet[0].item()), y)
+
+    @property
+    def mll(self) -> float:
+        """quick_inverse.py:37-38."""
+        return 0.5 * (-self.quad - self.logdet)
+
+    def propose(self, cur_leaf_vectors, new_leaf_vectors) -> float:
+        """MLL the chain would have after swapping the old tree's (scaled) leaf vectors for the new tree's
+        (bark_sampler.py:238-256).  Does not modify the state; call `accept()` to commit."""
+        import torch
+
+        lib = _lib.lib()
+        U_old, U_new = _dev64(cur_leaf_vectors), _dev64(new_leaf_vectors)
+        if U_old.shape[0] != self.N or U_new.shape[0] != self.N:
+            raise ValueError("leaf vectors must have N rows")
+        r_old, r_new = U_old.shape[1], U_new.shape[1]
+        if r_old + r_new > 64:
+            raise ValueError(f"tree swap supports at most 64 leaf vectors in total (got {r_old + r_new})")
+        U = torch.cat([U_old, U_new], dim=1).contiguous()
+        r = r_old + r_new
+        ws = torch.empty(int(lib.bark_lowrank_workspace_bytes(self.N, r)), dtype=torch.uint8, device=U.device)
+        scalars = torch.empty(2, dtype=torch.float64, device=U.device)
+        _lib.check(lib.bark_lowrank_swap_eval_hip(_lib.ptr(self.K_inv), self.N, _lib.ptr(U), r_old, r_new,
+                                                  _lib.ptr(self.y), _lib.ptr(scalars), _lib.ptr(ws), ws.numel(),
+                                                  _lib.stream_ptr()))
+        dquad, dlogdet = (float(v) for v in scalars.cpu().numpy())
+        self._pending = (ws, r, self.quad - dquad, self.logdet + dlogdet)
+        return 0.5 * (-(self.quad - dquad) - (self.logdet + dlogdet))
+
+    def accept(self) -> None:
+        """Commit the last proposal: K_inv <- K_inv - Y (C+G)^-1 Y' (bark_sampler.py:259-264)."""
+        if self._pending is None:
+            raise RuntimeError("accept() without a pending propose()")
+        ws, r, quad, logdet = self._pending
+        _lib.check(_lib.lib().bark_lowrank_swap_apply_hip(_lib.ptr(self.K_inv), self.N, r, _lib.ptr(ws),
+                                                          _lib.ptr(self.K_inv), _lib.stream_ptr()))
+        self.quad, self.logdet = quad, logdet
+        self._pending = None
+
+    def propose_tree(self, old_nodes, new_nodes, X, feat_types, scale: float, m: int) -> float:
+        """Convenience for bark_sampler.py:233-256: leaf vectors of both trees (GPU walk), scaled by
+        s_sqrtm = sqrt(scale / m), then `propose`."""
+        s = float(np.sqrt(scale / m))
+        cur = get_leaf_vectors(old_nodes, X, feat_types)
+        new = get_leaf_vectors(new_nodes, X, feat_types)
+        return self.propose(cur * s, new * s)

@@ -179,6 +179,19 @@ int bark_lowrank_update_hip(const double *K_inv, int64_t N, const double *U, int
                             double *K_out, double *logabsdet_out, void *workspace, size_t workspace_bytes,
                             void *stream);
 
+/* Fused tree swap for the sampler's per-tree step (bark_sampler.py:233-257): the reference chains
+ * subtract(U_old) -> add(U_new) -> mll on K_inv (about nine passes over the N x N matrix) before it can
+ * accept or reject.  With U = [U_old U_new] (N x (r_old + r_new), r_old + r_new <= 64), C = diag(-I, +I):
+ *   eval : ONE pass, Y = K_inv U; scalars_out[0] = v'(C+G)^-1 v  (v = Y'y, G = U'Y)  so that
+ *          y'K'^-1 y = y'K^-1 y - scalars_out[0];   scalars_out[1] = log|det(C+G)| = log|K'| - log|K|
+ *   apply: K_out = K_inv - Y (C+G)^-1 Y'   from the workspace left by eval (accepted proposals only).
+ * K_inv symmetric; workspace >= bark_lowrank_workspace_bytes(N, r_old + r_new). */
+int bark_lowrank_swap_eval_hip(const double *K_inv, int64_t N, const double *U, int64_t r_old, int64_t r_new,
+                               const double *y, double *scalars_out, void *workspace, size_t workspace_bytes,
+                               void *stream);
+int bark_lowrank_swap_apply_hip(const double *K_inv, int64_t N, int64_t r, const void *workspace, double *K_out,
+                                void *stream);
+
 /* quick_inverse.py:37-38  mll(K_inv, K_logdet, y) = 0.5 * (-y' K_inv y - K_logdet), on device. */
 int bark_quadform_hip(const double *K_inv, const double *y, int64_t N, double *out, void *stream);
 

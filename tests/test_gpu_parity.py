@@ -298,6 +298,46 @@ def test_g2_sampler_tree_swap_chain_on_device(B):
     assert np.isclose(float(qi.mll(inv2, det2, y)), want, rtol=1e-10)
 
 
+def test_fused_tree_swap_matches_reference_chain(B):
+    """ChainState.propose/accept vs the reference's subtract -> add -> mll chain (bark_sampler.py:233-264),
+    evaluated by the oracle, over a sequence of tree swaps; K_inv stays resident on the GPU."""
+    rng = np.random.default_rng(8)
+    X, y, bounds, ft = B.syn.mixed_problem(400, seed=8)
+    m, scale, noise = 20, 1.3, 0.1
+    forest = B.syn.sample_prior_forests(1, m, bounds, ft, seed=8)[0]
+    fresh = B.syn.sample_prior_forests(1, m, bounds, ft, seed=9, alpha=0.95, beta=1.0)[0]
+    state = B.fit.ChainState.from_forest(forest, noise, scale, X, y, ft)
+    # oracle state, exactly as bark_sampler.py:153-162
+    K = scale * B.orc.forest_gram_matrix(forest, X, X, ft) + (1e-6 + noise) * np.eye(400)
+    K_inv = np.linalg.inv(K)
+    logdet = np.linalg.slogdet(K)[1]
+    assert np.isclose(state.mll, B.orc.mll(K_inv, logdet, y), rtol=1e-10)
+    s = np.sqrt(scale / m)
+    for t_idx in range(6):
+        new_nodes = fresh[t_idx]
+        cur_lv = s * B.orc.get_leaf_vectors(forest[t_idx], X, ft)
+        new_lv = s * B.orc.get_leaf_vectors(new_nodes, X, ft)
+        inv1 = B.orc.low_rank_inv_update(K_inv, cur_lv, subtract=True)
+        det1 = B.orc.low_rank_det_update(K_inv, cur_lv, logdet, subtract=True)
+        inv2 = B.orc.low_rank_inv_update(inv1, new_lv)
+        det2 = B.orc.low_rank_det_update(inv1, new_lv, det1)
+        want = B.orc.mll(inv2, det2, y)
+        got = state.propose_tree(forest[t_idx], new_nodes, X, ft, scale, m)
+        assert np.isclose(got, want, rtol=1e-9, atol=1e-9), (t_idx, got, want)
+        if rng.uniform() < 0.7:  # accept
+            state.accept()
+            K_inv, logdet = inv2, det2
+            forest = forest.copy()
+            forest[t_idx] = new_nodes
+        assert np.isclose(state.mll, B.orc.mll(K_inv, logdet, y), rtol=1e-9)
+    # after the swaps the resident inverse is the exact inverse of the current forest's kernel
+    K = scale * B.orc.forest_gram_matrix(forest, X, X, ft) + (1e-6 + noise) * np.eye(400)
+    assert np.allclose(state.K_inv.cpu().numpy(), np.linalg.inv(K), rtol=1e-7, atol=1e-8)
+    assert np.isclose(state.logdet, np.linalg.slogdet(K)[1], rtol=1e-10)
+    with pytest.raises(RuntimeError):
+        state.accept()
+
+
 def test_woodbury_large_against_oracle(B):
     """N = 1500, r = 7 / 33 / 64: one-hot style and dense U, symmetric SPD K_inv."""
     rng = np.random.default_rng(3)
