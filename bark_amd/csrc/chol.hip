@@ -53,6 +53,7 @@ constexpr int THREADS = 256;
 #ifndef BARK_PANEL_DMA
 #define BARK_PANEL_DMA 1
 #endif
+// timing-only ablation builds of the panel loop (results invalid): 3 = no DMA issue, 4 = no DMA, no barrier
 #ifndef BARK_ABLATE
 #define BARK_ABLATE 0
 #endif
@@ -89,9 +90,6 @@ struct StageRegs {
 // global -> registers: stage kt of both panels; thread (lrow, lcol) moves 4 x 16 B per operand
 __device__ __forceinline__ void stage_load(StageRegs &r, const double *__restrict__ A, long lda,
                                            const double *__restrict__ B, long ldb, int kt, int lrow, int lcol) {
-#if BARK_ABLATE >= 1  // timing-only build: no global loads (results are garbage)
-    if (kt > 0) { asm volatile("" : "+v"(r.a0), "+v"(r.b0)); return; }
-#endif
     const double *a = A + ((long)kt * BK + lrow) * lda + lcol;
     const double *b = B + ((long)kt * BK + lrow) * ldb + lcol;
     r.a0 = *reinterpret_cast<const f64x2 *>(a);
@@ -106,9 +104,6 @@ __device__ __forceinline__ void stage_load(StageRegs &r, const double *__restric
 
 // registers -> LDS stage image As[k][LDS_LD] | Bs[k][LDS_LD]
 __device__ __forceinline__ void stage_store(const StageRegs &r, double *st, int lrow, int lcol) {
-#if BARK_ABLATE >= 2  // timing-only build: no LDS stage writes either
-    if (st != nullptr && lrow >= 0) { asm volatile("" ::"v"(r.a0), "v"(r.b0)); if (lcol >= 0) return; }
-#endif
     double *as = st + lrow * LDS_LD + lcol;
     double *bs = as + BK * LDS_LD;
     *reinterpret_cast<f64x2 *>(as) = r.a0;
