@@ -217,6 +217,32 @@ def test_wide_feature_matrix_walks_from_global_memory(B):
     assert np.array_equal(B.bf.batched_forest_gram_matrix(F, X, X, ft), B.orc.batched_forest_gram_matrix(F, X, X, ft))
 
 
+def test_input_layout_and_degenerate_shapes(B):
+    """What `DataFrame.to_numpy()` and sampler views hand over: Fortran order, float32, strided forests,
+    (N,) targets; and the smallest containers (one tree, one node slot)."""
+    X, y, bounds, ft = B.syn.mixed_problem(150, seed=12)
+    F = B.syn.sample_prior_forests(4, 9, bounds, ft, seed=12)
+    want_K = B.orc.batched_forest_gram_matrix(F, X, X, ft)
+    assert np.array_equal(B.bf.batched_forest_gram_matrix(F, np.asfortranarray(X), np.asfortranarray(X), ft), want_K)
+    X32 = X.astype(np.float32)
+    assert np.array_equal(B.bf.batched_forest_gram_matrix(F, X32, X32, ft),
+                          B.orc.batched_forest_gram_matrix(F, X32.astype(np.float64), X32.astype(np.float64), ft))
+    chains = np.stack([F, F[::-1]])[:, ::2]          # (2, 2, m, L) non-contiguous view, like forest[:, -1]
+    noise = np.array([[0.1, 0.2], [0.3, 0.15]])
+    got = B.fit.mll((chains, noise, None), (X, y[:, 0]), ft)   # y as (N,)
+    want = B.orc.batched_mll(np.ascontiguousarray(chains), noise, None, X, y, ft, include_scale=False, include_2pi=True)
+    assert np.allclose(got, want, rtol=MLL_RTOL, atol=MLL_ATOL)
+    one = F[:1, :1]                                     # a single tree
+    assert np.array_equal(B.bf.forest_gram_matrix(one[0], X, X, ft), B.orc.forest_gram_matrix(one[0], X, X, ft))
+    root_only = B.bf.create_empty_forest(3, node_limit=1)  # L = 1: every tree is just its root
+    K = B.bf.forest_gram_matrix(root_only, X, X, ft)
+    assert np.all(K == 1.0) and np.array_equal(B.bf.pass_through_forest(root_only, X, ft), np.zeros((150, 3), np.uint32))
+    with pytest.raises(ValueError):
+        B.bf.forest_gram_matrix(F[0], X[:, :3], X[:, :3], ft)   # wrong feature count
+    with pytest.raises(TypeError):
+        B.bf.forest_gram_matrix(np.zeros((2, 3)), X, X, ft)     # not a node record array
+
+
 def test_posterior_against_oracle_ragged(B):
     X, y, bounds, ft = B.syn.mixed_problem(300, seed=9)
     cand, _, _, _ = B.syn.mixed_problem(257, seed=10)
