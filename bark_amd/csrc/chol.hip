@@ -1131,6 +1131,7 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
 
     if (timing) {
         BARK_HIP_CHECK(hipStreamSynchronize(caller));
+        if (res) BARK_HIP_CHECK(hipStreamSynchronize(res->helper));
         auto span = [&](size_t a, size_t b_, float *acc) -> int {
             float ms = 0.f;
             BARK_HIP_CHECK(hipEventElapsedTime(&ms, ev[a], ev[b_]));
