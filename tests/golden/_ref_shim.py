@@ -52,10 +52,11 @@ def install():
         numba.prange = range
         placeholder = _TypePlaceholder()
         for name in (
-            "int64", "int32", "uint32", "uint8", "float32", "float64", "boolean",
+            "int64", "int32", "uint32", "uint8", "float32", "float64", "boolean", "bool_",
             "types", "typed", "typeof",
         ):
             setattr(numba, name, placeholder)
+        numba.__getattr__ = lambda name: placeholder  # any other type name used in a jitclass spec
         experimental = types.ModuleType("numba.experimental")
         experimental.jitclass = _identity_decorator
         numba.experimental = experimental

@@ -418,6 +418,80 @@ def g9_woodbury():
     save("g9_woodbury", {"src": "tests/bark_fitting/test_quick_inverse.py:13-52; quick_inverse.py:13-38"}, **out)
 
 
+def _bofire_stubs():
+    """Empty placeholder modules so that modules importing bofire at top level can be loaded."""
+    class _Cont:
+        pass
+
+    class _Cat:
+        pass
+
+    class _Disc:
+        pass
+
+    def _mod(name, **attrs):
+        mod = sys.modules.get(name) or types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(mod, k, v)
+        sys.modules[name] = mod
+        return mod
+
+    obj = type("_P", (), {})
+    _mod("bofire")
+    _mod("bofire.data_models")
+    _mod("bofire.data_models.domain")
+    _mod("bofire.data_models.domain.api", Domain=obj, Inputs=obj, Outputs=obj, Features=obj)
+    _mod("bofire.data_models.features")
+    _mod("bofire.data_models.features.api", CategoricalInput=_Cat, ContinuousInput=_Cont, ContinuousOutput=obj,
+         DiscreteInput=_Disc, AnyFeature=obj)
+    if "bofire_mixed.domain" not in sys.modules:
+        import importlib.util
+
+        _mod("bofire_mixed")
+        spec = importlib.util.spec_from_file_location("bofire_mixed.domain", "/root/reference/src/bofire_mixed/domain.py")
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules["bofire_mixed.domain"] = mod
+        spec.loader.exec_module(mod)
+
+
+def g10_mcmc_posterior_forests():
+    """Forests produced by the reference's own Metropolis-Hastings sampler
+    (bark_sampler.py:121-284 `_run_bark_sampler_multichain`): 2 chains x 3 samples after warm-up, on a mixed
+    cont/int/cat domain.  Their node containers carry the sampler's history (pruned sub-trees left behind as
+    inactive garbage, slots reused by later grows, `change`d rules) — the realistic input of the drop-in.
+    Expected outputs from the reference's forest.py / mcmc_record_mll arithmetic."""
+    _bofire_stubs()
+    import bark.fitting.bark_sampler as S
+
+    N, m = 40, 10
+    X, y, bounds, ft = mixed_problem(N, seed=1010, d_cont=3, n_cat=1, n_int=1, cats=4)
+    chains = 2
+    forest0 = np.stack([ref.empty_forest(m) for _ in range(chains)])
+    noise0 = np.array([0.1, 0.2])
+    scale0 = np.array([1.0, 1.0])
+    w = np.array([0.5, 0.5, 1.0])
+    params = S.BARKTrainParamsNumba(
+        warmup_steps=40, num_samples=3, steps_per_sample=6, num_chains=chains, alpha=0.95, beta=2.0,
+        proposal_weights=w / w.sum(), verbose=False, use_softplus_transform=True, sample_scale=False,
+        gamma_prior_shape=1.5, gamma_prior_rate=5.0)
+    np.random.seed(1010)
+    node_samples, noise_samples, scale_samples = S._run_bark_sampler_multichain(
+        forest0, noise0, scale0, X, y, bounds, ft, params)
+    flat = node_samples.reshape(-1, m, node_samples.shape[-1])
+    leaves = np.stack([F.pass_through_forest(f, X, ft) for f in flat])
+    K = F.batched_forest_gram_matrix(flat, X, X, ft)
+    K_nn = F.batched_forest_gram_matrix_no_null(flat, X, X, ft)
+    inactive_internal = int(((flat["active"] == 0) & (flat["is_leaf"] == 0) & (flat["left"] > 0)).sum())
+    save("g10_mcmc_posterior_forests",
+         {"src": "bark_sampler.py:121-284 run under the shim (np.random.seed(1010)); forest.py:58-111; "
+                 "mcmc_record_mll.py:57-74; bark_sampler.py:153-162",
+          "inactive_internal_slots": inactive_internal, "active_nodes_max": int(flat["active"].sum(-1).max())},
+         forest=raw(node_samples), noise=noise_samples, scale=scale_samples, X=X, y=y, bounds=bounds, feat_types=ft,
+         leaves=leaves, K=K, K_no_null=K_nn,
+         mll_example=mll_example(node_samples, noise_samples, X, y, ft),
+         mll_sampler=mll_sampler(flat, noise_samples.reshape(-1), scale_samples.reshape(-1), X, y, ft))
+
+
 if __name__ == "__main__":
     g1_kat_tree()
     g2_two_tree_kat()
@@ -428,6 +502,7 @@ if __name__ == "__main__":
     g7_tree_function()
     g8_batched_mll()
     g9_woodbury()
+    g10_mcmc_posterior_forests()
     # the reference tree must stay clean
     import subprocess
 

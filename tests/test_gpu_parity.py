@@ -146,6 +146,32 @@ def test_g8_batched_mll(B):
     assert np.array_equal(one, sa) and np.array_equal(three, sa)
 
 
+def test_g10_forests_from_the_reference_mcmc_sampler(B):
+    """Posterior forests produced by the reference's own sampler (bark_sampler.py:121-284)."""
+    g = load_golden("g10_mcmc_posterior_forests")
+    forest = raw(B, g["forest"])  # (chains, samples, m, L)
+    flat = forest.reshape(-1, *forest.shape[-2:])
+    X, y, ft = g["X"], g["y"], g["feat_types"]
+    for b in range(flat.shape[0]):
+        assert np.array_equal(B.bf.pass_through_forest(flat[b], X, ft), g["leaves"][b])
+    assert np.array_equal(B.bf.batched_forest_gram_matrix(flat, X, X, ft), g["K"])
+    assert np.array_equal(B.bf.batched_forest_gram_matrix_no_null(flat, X, X, ft), g["K_no_null"])
+    ex = B.fit.mll((forest, g["noise"], g["scale"]), (X, y), ft)
+    sa = B.fit.batched_mll(forest, g["noise"], g["scale"], X, y, ft, include_scale=True, include_2pi=False)
+    assert np.allclose(ex, g["mll_example"], rtol=MLL_RTOL, atol=MLL_ATOL)
+    assert np.allclose(sa, g["mll_sampler"], rtol=MLL_RTOL, atol=MLL_ATOL)
+    # continue one chain on the device: swap tree 0 of the last sample for tree 0 of the first sample
+    state = B.fit.ChainState.from_forest(flat[-1], float(g["noise"].reshape(-1)[-1]), float(g["scale"].reshape(-1)[-1]),
+                                         X, y, ft)
+    assert np.isclose(state.mll, g["mll_sampler"][-1], rtol=1e-9)
+    swapped = flat[-1].copy()
+    swapped[0] = flat[0][0]
+    new_mll = state.propose_tree(flat[-1][0], flat[0][0], X, ft, float(g["scale"].reshape(-1)[-1]), flat.shape[1])
+    want = B.orc.batched_mll(swapped[None], g["noise"].reshape(-1)[-1:], g["scale"].reshape(-1)[-1:], X, y, ft,
+                             include_scale=True, include_2pi=False)[0]
+    assert np.isclose(new_mll, want, rtol=1e-9)
+
+
 # ------------------------------------------------------------------ oracle on seeded inputs -------
 def test_c2_n1024_against_oracle(B):
     X, y, bounds, ft = B.syn.unit_cube_problem(1024, 8, seed=1024)

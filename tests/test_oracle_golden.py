@@ -152,3 +152,20 @@ def test_g9_woodbury():
         A = g[f"A{i}"]
         assert np.isclose(g[f"inv_add{i}"], np.linalg.inv(A + U @ U.T)).all()
         assert np.isclose(g[f"inv_sub{i}"], np.linalg.inv(A - U @ U.T)).all()
+
+
+def test_g10_forests_from_the_reference_mcmc_sampler():
+    """Posterior forests produced by the reference's own sampler (bark_sampler.py:121-284): node containers
+    with pruned garbage and reused slots."""
+    g = load_golden("g10_mcmc_posterior_forests")
+    forest = RAW(g["forest"])  # (chains, samples, m, L)
+    flat = forest.reshape(-1, *forest.shape[-2:])
+    X, y, ft = g["X"], g["y"], g["feat_types"]
+    for b in range(flat.shape[0]):
+        assert np.array_equal(orc.pass_through_forest(flat[b], X, ft), g["leaves"][b])
+        assert np.array_equal(orc.pass_through_forest_py(flat[b], X, ft), g["leaves"][b])
+    assert np.array_equal(orc.batched_forest_gram_matrix(flat, X, X, ft), g["K"])
+    assert np.array_equal(orc.batched_forest_gram_matrix_no_null(flat, X, X, ft), g["K_no_null"])
+    ex = orc.batched_mll(forest, g["noise"], None, X, y, ft, include_scale=False, include_2pi=True)
+    sa = orc.batched_mll(forest, g["noise"], g["scale"], X, y, ft, include_scale=True, include_2pi=False)
+    assert np.allclose(ex, g["mll_example"], rtol=1e-12) and np.allclose(sa, g["mll_sampler"], rtol=1e-12)
