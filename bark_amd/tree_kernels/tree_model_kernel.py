@@ -1,43 +1,63 @@
-"""Drop-in for `bark.tree_kernels.tree_model_kernel.TreeAgreementKernel`
-(reference: src/bark/tree_kernels/tree_model_kernel.py:8-23).
+"""GPU-backed tree-agreement kernel for gpytorch-style callers.
 
-The reference subclasses `gpytorch.kernels.Kernel`; gpytorch is optional here (absent from the
-build image): with it installed the class is a real gpytorch kernel, without it the same
-`forward` is available on a plain object.  CUDA tensors stay on the device (no numpy round trip).
+Interface parity with `bark.tree_kernels.tree_model_kernel.TreeAgreementKernel`
+(reference: src/bark/tree_kernels/tree_model_kernel.py:8-23): constructed from a forest of node
+records and the feature-type array; `forward(x1, x2, diag=False)` returns the (N, M) leaf-coincidence
+Gram matrix as a torch tensor, or a vector of ones for `diag=True` (a point always shares its own leaf).
+
+Differences from the reference, all additive:
+  * the Gram matrix comes from the HIP kernels (`bark_amd.forest.forest_gram_matrix`);
+  * CUDA inputs are consumed and returned on the device — no `.numpy()` round trip inside botorch's
+    fitting loop; CPU tensors are accepted too and give CPU tensors back;
+  * gpytorch is optional (it is absent from the build image): when importable the class derives from
+    `gpytorch.kernels.Kernel`, otherwise from a bare stand-in, with the same `forward`.
 """
 
 from __future__ import annotations
 
-import numpy as np
 import torch
 
 from ..forest import forest_gram_matrix
 
-try:  # pragma: no cover - gpytorch is not installed in the build image
-    import gpytorch as _gpy
 
-    _Base = _gpy.kernels.Kernel
-except ImportError:
-    class _Base:  # minimal stand-in so the adaptor stays importable
-        def __init__(self, *args, **kwargs):
-            pass
+def _kernel_base():
+    try:  # pragma: no cover - gpytorch is not installed in the build image
+        from gpytorch.kernels import Kernel
+
+        return Kernel
+    except ImportError:
+        class _PlainKernel:
+            """Minimal base so the adaptor stays importable and callable without gpytorch."""
+
+            def __init__(self, *args, **kwargs):
+                del args, kwargs
+
+            def __call__(self, x1, x2=None, **kwargs):
+                return self.forward(x1, x1 if x2 is None else x2, **kwargs)
+
+        return _PlainKernel
 
 
-class TreeAgreementKernel(_Base):
+class TreeAgreementKernel(_kernel_base()):
+    #: the leaf-coincidence kernel depends on absolute positions, not on x1 - x2
     is_stationary = False
 
-    def __init__(self, forest: np.ndarray, feat_types: np.ndarray):
+    def __init__(self, forest, feat_types):
         super().__init__()
-        self.forest = forest
-        self.feat_types = feat_types
+        self.forest, self.feat_types = forest, feat_types
 
-    def forward(self, x1: torch.Tensor, x2: torch.Tensor, diag=False, **params):
-        if diag:  # tree_model_kernel.py:17-18
+    def _gram(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        on_device = a.is_cuda
+        if on_device:
+            left = a.detach()
+            right = left if b is a else b.detach()
+            return forest_gram_matrix(self.forest, left, right, self.feat_types)
+        left = a.detach().cpu().numpy()
+        right = left if b is a else b.detach().cpu().numpy()
+        return torch.from_numpy(forest_gram_matrix(self.forest, left, right, self.feat_types))
+
+    def forward(self, x1: torch.Tensor, x2: torch.Tensor, diag: bool = False, **params):
+        del params  # accepted for gpytorch's calling convention, unused (as in the reference)
+        if diag:  # K(x, x) = 1: every tree puts a point in the same leaf as itself
             return torch.ones(x1.shape[0])
-        if x1.is_cuda:
-            a = x1.detach()
-            b = a if x2 is x1 else x2.detach()
-            return forest_gram_matrix(self.forest, a, b, self.feat_types)
-        x1n = x1.detach().numpy()
-        x2n = x1n if x2 is x1 else x2.detach().numpy()
-        return torch.as_tensor(forest_gram_matrix(self.forest, x1n, x2n, self.feat_types))
+        return self._gram(x1, x2)
