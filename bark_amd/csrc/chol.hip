@@ -873,8 +873,12 @@ int get_device_res(DeviceRes **out, size_t n_events) {
 }
 
 int set_lds_limits() {
-    static bool done = false;
-    if (done) return BARK_OK;
+    // kernels using more than 64 KiB of dynamic LDS need the limit raised once per device
+    static bool done[32] = {};
+    int dev = 0;
+    BARK_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 32) return fail(BARK_ERR_ARG, "device index %d out of range", dev);
+    if (done[dev]) return BARK_OK;
     BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(diag_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)DIAG_LDS));
     BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(panel_kernel<0>),
@@ -891,7 +895,7 @@ int set_lds_limits() {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
     BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(solve_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
-    done = true;
+    done[dev] = true;
     return BARK_OK;
 }
 
