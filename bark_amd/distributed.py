@@ -43,3 +43,21 @@ def gather_mll(local, total: int, group=None):
     parts = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(parts, padded, group=group)
     return torch.cat([p[: h - l] for p, (l, h) in zip(parts, sizes)])
+
+
+def reduce_mixture(mu_local, var_local, total: int, group=None):
+    """Mixture-of-Gaussians moments over ALL forest samples when each rank holds the posterior (mu, var) of
+    its own shard of samples (tree_gps.py:116-131 applied to the union of the shards):
+
+        E[Y] = (1/total) sum_b mu_b ;   Var[Y] = (1/total) sum_b (var_b + mu_b^2) - E[Y]^2
+
+    One all-reduce(sum) of 2*C float64 partial sums (160 KB at C = 10^4) instead of gathering (B, C) arrays.
+    `mu_local`, `var_local`: (B_local, C) torch tensors on the backend's device."""
+    import torch
+    import torch.distributed as dist
+
+    partial = torch.stack([mu_local.sum(dim=0), (var_local + mu_local**2).sum(dim=0)])
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=group)
+    mean = partial[0] / total
+    return mean, partial[1] / total - mean**2

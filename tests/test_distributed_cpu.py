@@ -45,7 +45,14 @@ def _worker(rank, world, port, total, q):
     lo, hi = sr(total, rank, world)
     local = orc.batched_mll(F[lo:hi], noise[lo:hi], None, X, y, ft, include_scale=False, include_2pi=True)
     full = gather_mll(torch.from_numpy(local), total)
-    q.put((rank, full.numpy()))
+    # posterior mixture over the union of the shards (one all-reduce of 2*C partial sums)
+    from bark_amd.distributed import reduce_mixture
+
+    cand, _, _, _ = synthetic.mixed_problem(11, seed=4)
+    scale = np.linspace(0.8, 1.2, total)
+    mu, var = orc.forest_predict((F[lo:hi], noise[lo:hi], scale[lo:hi]), (X, y), cand, ft)
+    mix_mu, mix_var = reduce_mixture(torch.from_numpy(mu), torch.from_numpy(np.ascontiguousarray(var)), total)
+    q.put((rank, full.numpy(), mix_mu.numpy(), mix_var.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -62,7 +69,9 @@ def test_gather_mll_world2_gloo(total):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
     for p in procs:
         p.start()
-    results = dict(q.get(timeout=120) for _ in range(2))
+    got = [q.get(timeout=120) for _ in range(2)]
+    results = {r[0]: r[1] for r in got}
+    mixes = {r[0]: (r[2], r[3]) for r in got}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -71,3 +80,10 @@ def test_gather_mll_world2_gloo(total):
     want = orc.batched_mll(F, np.linspace(0.05, 0.2, total), None, X, y, ft, include_scale=False, include_2pi=True)
     for rank in (0, 1):
         assert np.array_equal(results[rank], want)
+    cand, _, _, _ = synthetic.mixed_problem(11, seed=4)
+    noise, scale = np.linspace(0.05, 0.2, total), np.linspace(0.8, 1.2, total)
+    mu, var = orc.forest_predict((F, noise, scale), (X, y), cand, ft)
+    want_mu, want_var = orc.mixture_of_gaussians_as_normal(mu, var)
+    for rank in (0, 1):
+        assert np.allclose(mixes[rank][0], want_mu, rtol=1e-12, atol=1e-14)
+        assert np.allclose(mixes[rank][1], want_var, rtol=1e-10, atol=1e-13)
