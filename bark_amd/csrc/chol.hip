@@ -6,16 +6,23 @@
 //   src/bark/tree_kernels/tree_gps.py:80-113    mu = K_xX K_s^-1 y ; var = scale - diag(K_xX K_s^-1 K_Xx)
 // The reference does LU `inv` + LU `slogdet` per forest; here every forest sample of a chunk is
 // factorised as K_s = U'U (U upper triangular, row-major) by a LEFT-LOOKING blocked Cholesky
-// whose three kernels advance all Bc matrices of the chunk in lock step (block size 128):
+// whose kernels advance all Bc matrices of the chunk in lock step (block size 128).  Block column j:
 //
 //   diag_kernel  (1 workgroup / matrix)   D = P_jj - U[j-1,j]'U[j-1,j]; U_jj = chol(D); W_j = U_jj^-1;
 //                                         z_j = W_j' y_j; logdet += 2 sum log diag; quad += |z_j|^2
+//        ||  (concurrently, helper stream)
 //   panel_kernel (1 workgroup / 128x128 tile) T[j,i] = A[j,i] - sum_{k<j} U[k,j]' U[k,i]   (fp64 MFMA, K = 128 j)
-//                                         plus the partial diagonal tile P_{j+1,j+1} (same sum, k < j)
-//   solve_kernel (1 workgroup / tile)     U[j,i] = W_j' T[j,i]  (MFMA, K = 128);  y_i -= U[j,i]' z_j
+//                                         plus the partial diagonal tile P_{j+1,j+1} (same sum, k < j).
+//                                         Panels are staged by LDS-DMA; in MLL-only sweeps A[j,i] is generated
+//                                         in the epilogue from the leaf codes (the Gram is never materialised).
+//                                         Under-filled steps use panel_split_kernel + panel_reduce_kernel (split-K).
+//        then
+//   solve_kernel (1 workgroup / tile)     U[j,i] = W_j' T[j,i]  (MFMA, K = 128, zero k-tiles of W_j skipped);
+//                                         y_i -= U[j,i]' z_j
 //
-// The candidate block of the posterior (K_Xx, N x C) is appended as extra block columns, so the
-// same sweep yields V = U^-T K_Xx; then mu = V'z and var = scale - colsumsq(V).
+// The candidate block of the posterior (K_Xx, N x C) — or an identity block for the explicit inverse — is
+// appended as extra block columns, so the same sweep yields V = U^-T K_Xx; then mu = V'z,
+// var = scale - colsumsq(V), and optionally the full covariance / K_s^-1 = V'V (vtv_kernel).
 //
 // Why left-looking: every U tile is written once and each trailing tile is accumulated in
 // registers over the whole K range, instead of a read-modify-write of the trailing matrix per
