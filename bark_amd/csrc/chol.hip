@@ -906,6 +906,130 @@ int set_lds_limits() {
     return BARK_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sweep: the factorisation of one chunk of resident matrices, shared by the dense MLL / posterior entry
+// point and the leaf-space entry point.  The caller fills the matrices (and right-hand sides), then calls
+// step(j) for every block column.
+// ---------------------------------------------------------------------------------------------
+struct Sweep {
+    Mats p;
+    hipStream_t main = nullptr, panel = nullptr;  // panel == main: no overlap
+    DeviceRes *res = nullptr;
+    int nrb = 0, ncb = 0;
+    bool fused = false, splitk = false;
+    int rep = 0;
+    double *slabs = nullptr;
+    // timing mode only: one event pair per launch, recorded on the stream of the launch
+    bool timed = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<size_t> gram_marks, diag_marks, panel_marks, solve_marks;
+    double panel_flops = 0.0, solve_flops = 0.0;
+
+    int mark_on(hipStream_t s) {
+        if (!timed) return BARK_OK;
+        hipEvent_t e;
+        BARK_HIP_CHECK(hipEventCreate(&e));
+        BARK_HIP_CHECK(hipEventRecord(e, s));
+        ev.push_back(e);
+        return BARK_OK;
+    }
+
+    // block column j of the current chunk (p.Bc matrices): diag || panel, then solve
+    int step(int j) {
+        hipStream_t s = main, ps = panel;
+        const int bc = p.Bc;
+        const int n_right = ncb - j - 1;
+        const int n_diag = (j + 1 < nrb) ? 1 : 0;
+        const bool has_panel = j >= 1 && n_right + n_diag > 0;
+        const bool forked = ps != s;
+        int r;
+        if (forked && has_panel) {  // fork: panel(j) waits for everything enqueued so far (solve(j-1))
+            BARK_HIP_CHECK(hipEventRecord(res->events[2 * j], s));
+            BARK_HIP_CHECK(hipStreamWaitEvent(ps, res->events[2 * j], 0));
+        }
+        if (timed) diag_marks.push_back(ev.size());
+        if ((r = mark_on(s))) return r;
+        hipLaunchKernelGGL(diag_kernel, dim3((unsigned)bc), dim3(THREADS), DIAG_LDS, s, p, j);
+        BARK_LAUNCH_CHECK();
+        if ((r = mark_on(s))) return r;
+        if (has_panel) {
+            if (timed) panel_marks.push_back(ev.size());
+            if ((r = mark_on(ps))) return r;
+            const int n_tiles = n_right + n_diag;
+            const dim3 pg(xcd_grid(n_tiles, bc));
+            const size_t pl = GEMM_LDS + debug_extra_lds();
+            int S = 1;  // split-K factor: fill ~SPLITK_SLOTS workgroup slots, >= 1 block row per slab
+            if (splitk && n_tiles * bc < SPLITK_SLOTS / 2) {
+                S = SPLITK_SLOTS / (n_tiles * bc);
+                if (S > j) S = j;
+                if (S > SPLITK_MAX) S = SPLITK_MAX;
+            }
+            if (S > 1) {
+                hipLaunchKernelGGL(panel_split_kernel, dim3(xcd_grid(n_tiles * S, bc)), dim3(THREADS), GEMM_LDS, ps, p, j,
+                                   n_right, n_tiles, S, slabs);
+                BARK_LAUNCH_CHECK();
+                hipLaunchKernelGGL(panel_reduce_kernel, dim3((unsigned)n_tiles, (unsigned)bc), dim3(THREADS), 0, ps, p, j,
+                                   n_right, n_tiles, S, slabs);
+            } else if (!fused)
+                hipLaunchKernelGGL(panel_kernel<0>, pg, dim3(THREADS), pl, ps, p, j, n_right, n_tiles);
+            else if (rep == REP_BITS)
+                hipLaunchKernelGGL(panel_kernel<1 + REP_BITS>, pg, dim3(THREADS), pl, ps, p, j, n_right, n_tiles);
+            else if (rep == REP_BYTES7)
+                hipLaunchKernelGGL(panel_kernel<1 + REP_BYTES7>, pg, dim3(THREADS), pl, ps, p, j, n_right, n_tiles);
+            else
+                hipLaunchKernelGGL(panel_kernel<1 + REP_BYTES8>, pg, dim3(THREADS), pl, ps, p, j, n_right, n_tiles);
+            BARK_LAUNCH_CHECK();
+            if ((r = mark_on(ps))) return r;
+            panel_flops += 2.0 * NB * NB * (double)(j * NB) * (double)(n_right + n_diag) * (double)bc;
+            if (forked) {  // join: solve(j) (and diag(j+1)) need the panel's tiles
+                BARK_HIP_CHECK(hipEventRecord(res->events[2 * j + 1], ps));
+                BARK_HIP_CHECK(hipStreamWaitEvent(s, res->events[2 * j + 1], 0));
+            }
+        }
+        if (n_right > 0) {
+            if (timed) solve_marks.push_back(ev.size());
+            if ((r = mark_on(s))) return r;
+            hipLaunchKernelGGL(solve_kernel, dim3(xcd_grid(n_right, bc)), dim3(THREADS), GEMM_LDS, s, p, j, n_right);
+            BARK_LAUNCH_CHECK();
+            if ((r = mark_on(s))) return r;
+            solve_flops += 2.0 * NB * NB * (double)NB * (double)n_right * (double)bc;
+        }
+        return BARK_OK;
+    }
+
+    // fill *t from the recorded events (synchronises); [t_begin, t_end] bracket the whole call on `caller`
+    int report(bark_mll_timing *t, size_t t_begin, size_t t_end, hipStream_t caller) {
+        BARK_HIP_CHECK(hipStreamSynchronize(caller));
+        if (res) BARK_HIP_CHECK(hipStreamSynchronize(res->helper));
+        int r;
+        auto span = [&](size_t a, size_t b_, float *acc) -> int {
+            float ms = 0.f;
+            BARK_HIP_CHECK(hipEventElapsedTime(&ms, ev[a], ev[b_]));
+            *acc += ms;
+            return BARK_OK;
+        };
+        t->total_ms = t->gram_ms = t->chol_ms = t->diag_ms = t->panel_ms = t->solve_ms = 0.f;
+        if ((r = span(t_begin, t_end, &t->total_ms))) return r;
+        for (size_t a : gram_marks)
+            if ((r = span(a, a + 1, &t->gram_ms))) return r;
+        for (size_t a : diag_marks)
+            if ((r = span(a, a + 1, &t->diag_ms))) return r;
+        for (size_t a : panel_marks)
+            if ((r = span(a, a + 1, &t->panel_ms))) return r;
+        for (size_t a : solve_marks)
+            if ((r = span(a, a + 1, &t->solve_ms))) return r;
+        t->chol_ms = t->total_ms - t->gram_ms;
+        t->n_diag_launches = (int64_t)diag_marks.size();
+        t->n_panel_launches = (int64_t)panel_marks.size();
+        t->n_solve_launches = (int64_t)solve_marks.size();
+        t->panel_flops = panel_flops;
+        t->solve_flops = solve_flops;
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        ev.clear();
+        return BARK_OK;
+    }
+};
+
 }  // namespace
 }  // namespace bark
 
@@ -964,15 +1088,21 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
     DeviceRes *res = nullptr;
     if (overlap_env && (rc = get_device_res(&res, (size_t)2 * nrb))) return rc;
 
-    struct Chunk {
-        Mats p;
-        uint32_t *leafx, *leafc;
-        hipStream_t main, panel;
-        int64_t c0, bc;
-    } ln;
+    Sweep sw;
+    sw.res = res;
+    sw.nrb = nrb;
+    sw.ncb = ncb;
+    sw.fused = fused;
+    sw.splitk = splitk;
+    sw.rep = rep;
+    sw.slabs = slabs;
+    sw.timed = timing != nullptr;
+    sw.main = caller;
+    sw.panel = res ? res->helper : caller;
+    uint32_t *leafx, *leafc;
     {
         char *ws = static_cast<char *>(workspace);
-        Mats &p = ln.p;
+        Mats &p = sw.p;
         p.A = reinterpret_cast<double *>(ws + L.off_A);
         p.ld = L.ld;
         p.bstride = L.npad * L.ld;
@@ -984,44 +1114,28 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
         p.nW = words;
         p.m = (int)m;
         p.N = (int)N;
-        ln.leafx = reinterpret_cast<uint32_t *>(ws + L.off_leafx);
-        ln.leafc = reinterpret_cast<uint32_t *>(ws + L.off_leafc);
-        ln.main = caller;
-        ln.panel = res ? res->helper : caller;
+        leafx = reinterpret_cast<uint32_t *>(ws + L.off_leafx);
+        leafc = reinterpret_cast<uint32_t *>(ws + L.off_leafc);
     }
 
-    // timing mode only: one event pair per launch, on the stream of the launch
-    std::vector<hipEvent_t> ev;
-    auto mark_on = [&](hipStream_t s) -> int {
-        if (!timing) return BARK_OK;
-        hipEvent_t e;
-        BARK_HIP_CHECK(hipEventCreate(&e));
-        BARK_HIP_CHECK(hipEventRecord(e, s));
-        ev.push_back(e);
-        return BARK_OK;
-    };
-    std::vector<size_t> gram_marks, diag_marks, panel_marks, solve_marks;
-    double panel_flops = 0.0, solve_flops = 0.0;
-
-    auto prologue = [&]() -> int {  // leaf walk, Gram fill, right-hand sides of one chunk
-        Mats &p = ln.p;
-        hipStream_t s = ln.main;
-        const int64_t c0 = ln.c0, bc = ln.bc;
+    auto prologue = [&](int64_t c0, int64_t bc) -> int {  // leaf walk, Gram fill, right-hand sides of one chunk
+        Mats &p = sw.p;
+        hipStream_t s = sw.main;
         bark_pack_info sub = *info;
         sub.B = bc;
         const char *packed_c = static_cast<const char *>(packed) + (size_t)c0 * m * info->stride * 16;
         p.info = info_out + c0;
         p.Bc = (int)bc;
-        p.leafx = fused ? ln.leafx : nullptr;
+        p.leafx = fused ? leafx : nullptr;
         p.scale = use_scale ? scale + c0 : nullptr;
         p.shift = shift ? shift + c0 : nullptr;
         p.noise = noise + c0;
         int r;
-        if (timing) gram_marks.push_back(ev.size());
-        if ((r = mark_on(s))) return r;
-        if ((r = bark_leaf_codes_hip(packed_c, &sub, X, N, d, ln.leafx, s))) return r;
+        if (sw.timed) sw.gram_marks.push_back(sw.ev.size());
+        if ((r = sw.mark_on(s))) return r;
+        if ((r = bark_leaf_codes_hip(packed_c, &sub, X, N, d, leafx, s))) return r;
         const int fill_rows = fused ? (int)(L.npad < 2 * NB ? L.npad : 2 * NB) : (int)L.npad;
-        r = launch_gram(ln.leafx, (int)L.npad, ln.leafx, (int)L.npad, bc, m, (int)N, (int)N, fill_rows, (int)L.npad,
+        r = launch_gram(leafx, (int)L.npad, leafx, (int)L.npad, bc, m, (int)N, (int)N, fill_rows, (int)L.npad,
                         p.shift, p.scale, p.noise, p.A, L.ld, p.bstride, true, true, rep, words, s);
         if (r) return r;
         if (rhs_identity) {
@@ -1029,84 +1143,20 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
             hipLaunchKernelGGL(identity_rhs_kernel, g, dim3(256), 0, s, p, (int)N, (int)L.cpad);
             BARK_LAUNCH_CHECK();
         } else if (C > 0) {
-            if ((r = bark_leaf_codes_hip(packed_c, &sub, cand, C, d, ln.leafc, s))) return r;
-            r = launch_gram(ln.leafx, (int)L.npad, ln.leafc, (int)L.cpad, bc, m, (int)N, (int)C, (int)L.npad,
+            if ((r = bark_leaf_codes_hip(packed_c, &sub, cand, C, d, leafc, s))) return r;
+            r = launch_gram(leafx, (int)L.npad, leafc, (int)L.cpad, bc, m, (int)N, (int)C, (int)L.npad,
                             (int)L.cpad, p.shift, scale + c0, nullptr, p.A + L.npad, L.ld, p.bstride, false, false, rep, words, s);
             if (r) return r;
         }
         dim3 g((unsigned)((L.npad + 255) / 256), (unsigned)bc);
         hipLaunchKernelGGL(init_rhs_kernel, g, dim3(256), 0, s, y, (int)N, (int)L.npad, p.yz, p.accum, p.info);
         BARK_LAUNCH_CHECK();
-        return mark_on(s);
+        return sw.mark_on(s);
     };
 
-    auto step = [&](int j) -> int {  // block column j of one chunk: diag || panel, then solve
-        Mats &p = ln.p;
-        hipStream_t s = ln.main, ps = ln.panel;
-        const int bc = (int)ln.bc;
-        const int n_right = ncb - j - 1;
-        const int n_diag = (j + 1 < nrb) ? 1 : 0;
-        const bool has_panel = j >= 1 && n_right + n_diag > 0;
-        const bool forked = ps != s;
-        int r;
-        if (forked && has_panel) {  // fork: panel(j) waits for everything enqueued so far (solve(j-1))
-            BARK_HIP_CHECK(hipEventRecord(res->events[2 * j], s));
-            BARK_HIP_CHECK(hipStreamWaitEvent(ps, res->events[2 * j], 0));
-        }
-        if (timing) diag_marks.push_back(ev.size());
-        if ((r = mark_on(s))) return r;
-        hipLaunchKernelGGL(diag_kernel, dim3((unsigned)bc), dim3(THREADS), DIAG_LDS, s, p, j);
-        BARK_LAUNCH_CHECK();
-        if ((r = mark_on(s))) return r;
-        if (has_panel) {
-            if (timing) panel_marks.push_back(ev.size());
-            if ((r = mark_on(ps))) return r;
-            const int n_tiles = n_right + n_diag;
-            const dim3 pg(xcd_grid(n_tiles, bc));
-            const size_t pl = GEMM_LDS + debug_extra_lds();
-            int S = 1;  // split-K factor: fill ~SPLITK_SLOTS workgroup slots, >= 1 block row per slab
-            if (splitk && n_tiles * bc < SPLITK_SLOTS / 2) {
-                S = SPLITK_SLOTS / (n_tiles * bc);
-                if (S > j) S = j;
-                if (S > SPLITK_MAX) S = SPLITK_MAX;
-            }
-            if (S > 1) {
-                hipLaunchKernelGGL(panel_split_kernel, dim3(xcd_grid(n_tiles * S, bc)), dim3(THREADS), GEMM_LDS, ps, p, j,
-                                   n_right, n_tiles, S, slabs);
-                BARK_LAUNCH_CHECK();
-                hipLaunchKernelGGL(panel_reduce_kernel, dim3((unsigned)n_tiles, (unsigned)bc), dim3(THREADS), 0, ps, p, j,
-                                   n_right, n_tiles, S, slabs);
-            } else if (!fused)
-                hipLaunchKernelGGL(panel_kernel<0>, pg, dim3(THREADS), pl, ps, p, j, n_right, n_tiles);
-            else if (rep == REP_BITS)
-                hipLaunchKernelGGL(panel_kernel<1 + REP_BITS>, pg, dim3(THREADS), pl, ps, p, j, n_right, n_tiles);
-            else if (rep == REP_BYTES7)
-                hipLaunchKernelGGL(panel_kernel<1 + REP_BYTES7>, pg, dim3(THREADS), pl, ps, p, j, n_right, n_tiles);
-            else
-                hipLaunchKernelGGL(panel_kernel<1 + REP_BYTES8>, pg, dim3(THREADS), pl, ps, p, j, n_right, n_tiles);
-            BARK_LAUNCH_CHECK();
-            if ((r = mark_on(ps))) return r;
-            panel_flops += 2.0 * NB * NB * (double)(j * NB) * (double)(n_right + n_diag) * (double)bc;
-            if (forked) {  // join: solve(j) (and diag(j+1)) need the panel's tiles
-                BARK_HIP_CHECK(hipEventRecord(res->events[2 * j + 1], ps));
-                BARK_HIP_CHECK(hipStreamWaitEvent(s, res->events[2 * j + 1], 0));
-            }
-        }
-        if (n_right > 0) {
-            if (timing) solve_marks.push_back(ev.size());
-            if ((r = mark_on(s))) return r;
-            hipLaunchKernelGGL(solve_kernel, dim3(xcd_grid(n_right, bc)), dim3(THREADS), GEMM_LDS, s, p, j, n_right);
-            BARK_LAUNCH_CHECK();
-            if ((r = mark_on(s))) return r;
-            solve_flops += 2.0 * NB * NB * (double)NB * (double)n_right * (double)bc;
-        }
-        return BARK_OK;
-    };
-
-    auto epilogue = [&]() -> int {  // MLL and posterior reductions of one chunk
-        Mats &p = ln.p;
-        hipStream_t s = ln.main;
-        const int64_t c0 = ln.c0, bc = ln.bc;
+    auto epilogue = [&](int64_t c0, int64_t bc) -> int {  // MLL and posterior reductions of one chunk
+        Mats &p = sw.p;
+        hipStream_t s = sw.main;
         hipLaunchKernelGGL(finish_mll_kernel, dim3((unsigned)((bc + 255) / 256)), dim3(256), 0, s, p.accum, (int)bc, (int)N,
                            (flags & BARK_MLL_INCLUDE_2PI) ? 1 : 0, mll_out + c0);
         BARK_LAUNCH_CHECK();
@@ -1127,46 +1177,18 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
         return BARK_OK;
     };
 
-    const size_t t_begin = ev.size();
-    if ((rc = mark_on(caller))) return rc;
+    const size_t t_begin = sw.ev.size();
+    if ((rc = sw.mark_on(caller))) return rc;
     for (int64_t c0 = 0; c0 < B; c0 += Bc) {  // chunks of Bc resident matrices, one after the other
-        ln.c0 = c0;
-        ln.bc = (B - c0 < Bc) ? (B - c0) : Bc;
-        if ((rc = prologue())) return rc;
+        const int64_t bc = (B - c0 < Bc) ? (B - c0) : Bc;
+        if ((rc = prologue(c0, bc))) return rc;
         for (int j = 0; j < nrb; ++j)
-            if ((rc = step(j))) return rc;
-        if ((rc = epilogue())) return rc;
+            if ((rc = sw.step(j))) return rc;
+        if ((rc = epilogue(c0, bc))) return rc;
     }
-    const size_t t_end = ev.size();
-    if ((rc = mark_on(caller))) return rc;
-
-    if (timing) {
-        BARK_HIP_CHECK(hipStreamSynchronize(caller));
-        if (res) BARK_HIP_CHECK(hipStreamSynchronize(res->helper));
-        auto span = [&](size_t a, size_t b_, float *acc) -> int {
-            float ms = 0.f;
-            BARK_HIP_CHECK(hipEventElapsedTime(&ms, ev[a], ev[b_]));
-            *acc += ms;
-            return BARK_OK;
-        };
-        timing->total_ms = timing->gram_ms = timing->chol_ms = timing->diag_ms = timing->panel_ms = timing->solve_ms = 0.f;
-        if ((rc = span(t_begin, t_end, &timing->total_ms))) return rc;
-        for (size_t a : gram_marks)
-            if ((rc = span(a, a + 1, &timing->gram_ms))) return rc;
-        for (size_t a : diag_marks)
-            if ((rc = span(a, a + 1, &timing->diag_ms))) return rc;
-        for (size_t a : panel_marks)
-            if ((rc = span(a, a + 1, &timing->panel_ms))) return rc;
-        for (size_t a : solve_marks)
-            if ((rc = span(a, a + 1, &timing->solve_ms))) return rc;
-        timing->chol_ms = timing->total_ms - timing->gram_ms;
-        timing->n_diag_launches = (int64_t)diag_marks.size();
-        timing->n_panel_launches = (int64_t)panel_marks.size();
-        timing->n_solve_launches = (int64_t)solve_marks.size();
-        timing->panel_flops = panel_flops;
-        timing->solve_flops = solve_flops;
-        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
-    }
+    const size_t t_end = sw.ev.size();
+    if ((rc = sw.mark_on(caller))) return rc;
+    if (timing) return sw.report(timing, t_begin, t_end, caller);
     return BARK_OK;
 }
 
