@@ -42,6 +42,15 @@
 
 namespace bark {
 
+int walk_one_hot(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d, int words,
+                 uint32_t *out, hipStream_t stream);
+int leafspace_prepare(const uint32_t *codes, int W, int npad, unsigned long long *planes, int R, int Rpad,
+                      const double *noise, const double *scale, int m, int bc, double *A, long ld, long bstride,
+                      const double *y, int N, double *yz, double *accum, int32_t *info, hipStream_t s);
+int leafspace_sumsq(const double *y, int N, double *out, hipStream_t s);
+int leafspace_finish(const double *accum, const double *yy, const double *noise, const double *scale, int m, int bc, int N,
+                     int include_2pi, double *mll, hipStream_t s);
+
 int launch_gram(const uint32_t *leaf1, int npad1, const uint32_t *leaf2, int npad2, int64_t B, int64_t m, int N, int M,
                 int Nout, int Mout, const double *shift, const double *scale, const double *noise, double *out, int64_t ld,
                 int64_t batch_stride, bool pad_identity, bool upper_only, int rep, int words, hipStream_t stream);
@@ -1189,6 +1198,114 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
     const size_t t_end = sw.ev.size();
     if ((rc = sw.mark_on(caller))) return rc;
     if (timing) return sw.report(timing, t_begin, t_end, caller);
+    return BARK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Leaf-space MLL (kernels in leafspace.hip): factorises I_R + c Z'Z (R x R) instead of K_s (N x N).
+// ---------------------------------------------------------------------------------------------
+struct LeafLayout {
+    Layout L;         // the R x R sweep workspace (N := R, no candidates)
+    int64_t R, Rpad, W, npad, Q;
+    size_t off_codes, off_planes, off_yy, total;
+};
+
+static LeafLayout make_leaf_layout(int64_t N, int64_t max_bits, int64_t m, int64_t Bc) {
+    LeafLayout g;
+    g.R = max_bits;
+    g.Rpad = round_up(max_bits, NB);
+    g.W = (max_bits + 31) / 32;
+    g.npad = round_up(N, NB);
+    g.Q = g.npad / 64;
+    g.L = make_layout(max_bits, 0, m, Bc);
+    size_t o = g.L.total;
+    g.off_codes = o;
+    o = align256(o + (size_t)Bc * g.W * g.npad * sizeof(uint32_t));
+    g.off_planes = o;
+    o = align256(o + (size_t)Bc * 32 * g.W * g.Q * sizeof(unsigned long long));
+    g.off_yy = o;
+    o = align256(o + 64);
+    g.total = o;
+    return g;
+}
+
+size_t bark_mll_leafspace_workspace_bytes(int64_t N, int64_t max_bits, int64_t m, int64_t Bc) {
+    if (N < 1 || max_bits < 1 || m < 1 || Bc < 1) return 0;
+    return make_leaf_layout(N, max_bits, m, Bc).total;
+}
+
+int bark_mll_leafspace_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
+                           const double *y, const double *noise, const double *scale, int flags, double *mll_out,
+                           int32_t *info_out, void *workspace, size_t workspace_bytes, int64_t Bc, void *stream_) {
+    error_buffer()[0] = 0;
+    if (!packed || !info || !X || !y || !noise || !mll_out || !info_out || !workspace)
+        return fail(BARK_ERR_ARG, "bark_mll_leafspace_hip: null argument");
+    const int64_t B = info->B, m = info->m;
+    if (N < 1 || d < 1 || B < 1 || Bc < 1 || N > (1 << 24))
+        return fail(BARK_ERR_ARG, "bark_mll_leafspace_hip: bad shape N=%lld d=%lld B=%lld Bc=%lld", (long long)N, (long long)d,
+                    (long long)B, (long long)Bc);
+    if ((flags & BARK_MLL_INCLUDE_SCALE) && !scale) return fail(BARK_ERR_ARG, "BARK_MLL_INCLUDE_SCALE without scale");
+    if (flags & BARK_MLL_RHS_IDENTITY) return fail(BARK_ERR_ARG, "leaf-space path computes the MLL only");
+    if (info->max_bits > 8192) return fail(BARK_ERR_ARG, "leaf-space path supports at most 8192 leaves per forest");
+    if (Bc > B) Bc = B;
+    if (Bc > 65535) Bc = 65535;
+    const LeafLayout g = make_leaf_layout(N, info->max_bits, m, Bc);
+    if (workspace_bytes < g.total) return fail(BARK_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", workspace_bytes, g.total);
+    if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(BARK_ERR_ARG, "workspace must be 256-byte aligned");
+    int rc = set_lds_limits();
+    if (rc) return rc;
+    hipStream_t caller = static_cast<hipStream_t>(stream_);
+    static const bool overlap_env = getenv("BARK_NO_DIAG_OVERLAP") == nullptr;
+    const int nrb = (int)(g.Rpad / NB);
+    DeviceRes *res = nullptr;
+    if (overlap_env && (rc = get_device_res(&res, (size_t)2 * nrb))) return rc;
+
+    char *ws = static_cast<char *>(workspace);
+    Sweep sw;
+    sw.res = res;
+    sw.nrb = sw.ncb = nrb;
+    sw.fused = false;
+    sw.splitk = g.L.splitk;
+    sw.slabs = reinterpret_cast<double *>(ws + g.L.off_slab);
+    sw.main = caller;
+    sw.panel = res ? res->helper : caller;
+    Mats &p = sw.p;
+    p.A = reinterpret_cast<double *>(ws + g.L.off_A);
+    p.ld = g.L.ld;
+    p.bstride = g.L.npad * g.L.ld;
+    p.W = reinterpret_cast<double *>(ws + g.L.off_W);
+    p.yz = reinterpret_cast<double *>(ws + g.L.off_yz);
+    p.accum = reinterpret_cast<double *>(ws + g.L.off_acc);
+    p.nrb = p.ncb = nrb;
+    p.leafx = nullptr;
+    p.scale = p.shift = p.noise = nullptr;
+    p.nW = 0;
+    p.m = (int)m;
+    p.N = (int)g.R;
+    uint32_t *codes = reinterpret_cast<uint32_t *>(ws + g.off_codes);
+    unsigned long long *planes = reinterpret_cast<unsigned long long *>(ws + g.off_planes);
+    double *yy = reinterpret_cast<double *>(ws + g.off_yy);
+    const bool use_scale = (flags & BARK_MLL_INCLUDE_SCALE) != 0;
+
+    if ((rc = leafspace_sumsq(y, (int)N, yy, caller))) return rc;
+    for (int64_t c0 = 0; c0 < B; c0 += Bc) {
+        const int64_t bc = (B - c0 < Bc) ? (B - c0) : Bc;
+        bark_pack_info sub = *info;
+        sub.B = bc;
+        const char *packed_c = static_cast<const char *>(packed) + (size_t)c0 * m * info->stride * 16;
+        p.info = info_out + c0;
+        p.Bc = (int)bc;
+        if ((rc = walk_one_hot(packed_c, &sub, X, N, d, (int)g.W, codes, caller))) return rc;
+        rc = leafspace_prepare(codes, (int)g.W, (int)g.npad, planes, (int)g.R, (int)g.Rpad, noise + c0,
+                               use_scale ? scale + c0 : nullptr, (int)m, (int)bc, p.A, p.ld, p.bstride, y, (int)N, p.yz,
+                               p.accum, p.info, caller);
+        if (rc) return rc;
+        for (int j = 0; j < nrb; ++j)
+            if ((rc = sw.step(j))) return rc;
+        rc = leafspace_finish(p.accum, yy, noise + c0, use_scale ? scale + c0 : nullptr, (int)m, (int)bc, (int)N,
+                              (flags & BARK_MLL_INCLUDE_2PI) ? 1 : 0, mll_out + c0, caller);
+        if (rc) return rc;
+    }
     return BARK_OK;
 }
 

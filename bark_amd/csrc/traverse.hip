@@ -116,13 +116,13 @@ __global__ __launch_bounds__(WALK_THREADS) void leaf_walk_kernel(const uint4 *__
 
 template <int MODE>
 int launch_walk(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d, uint32_t *out,
-                void *stream) {
+                void *stream, int force_words = 0) {
     if (!packed || !info || !X || !out) return fail(BARK_ERR_ARG, "leaf walk: null argument");
     if (N < 1 || d < 1 || N > (1 << 30)) return fail(BARK_ERR_ARG, "leaf walk: bad N=%lld d=%lld", (long long)N, (long long)d);
     if (info->B > 65535) return fail(BARK_ERR_ARG, "leaf walk: at most 65535 forests per call (got %lld)", (long long)info->B);
     const int64_t npad = bark_leaf_npad(N);
-    const int words = (int)bark_leaf_words(info);
-    if (MODE != 0 && words > MAX_LEAF_WORDS)
+    const int words = force_words ? force_words : (int)bark_leaf_words(info);
+    if (MODE != 0 && !force_words && words > MAX_LEAF_WORDS)
         return fail(BARK_ERR_ARG, "forest needs %d leaf-code words per point (max %d): too many leaves in total", words,
                     MAX_LEAF_WORDS);
     const int64_t extent = MODE != 0 ? npad : N;
@@ -142,6 +142,13 @@ int launch_walk(const void *packed, const bark_pack_info *info, const double *X,
 }
 
 }  // namespace
+
+// one-hot leaf code with `words` = ceil(max_bits / 32) planes, whatever encoding the Gram kernels would pick
+int walk_one_hot(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d, int words,
+                 uint32_t *out, hipStream_t stream) {
+    return launch_walk<2>(packed, info, X, N, d, out, stream, words);
+}
+
 }  // namespace bark
 
 using namespace bark;

@@ -162,17 +162,61 @@ def batched_kernel_inverse(forest, noise, scale, X, y, feat_types, *, no_null: b
     return K_inv.cpu().numpy(), K_inv_y.cpu().numpy(), logdet.cpu().numpy()
 
 
+def _run_leafspace(forest, noise, scale, X, y, feat_types, flags, chunk=None):
+    """Leaf-space evaluation (bark_mll_leafspace_hip): R x R system instead of N x N."""
+    import torch
+
+    lib = _lib.lib()
+    ft = _feat_types(feat_types)
+    nodes = _as_nodes(forest, 2)
+    nodes3 = nodes.reshape(-1, *nodes.shape[-2:])
+    B = nodes3.shape[0]
+    Xd, _ = _points(X, ft.shape[0])
+    _check_categorical(Xd, ft)
+    N, d = Xd.shape
+    yd = _lib.to_device(y.detach() if _is_torch(y) else np.asarray(y, dtype=np.float64))
+    yd = yd.to(torch.float64).reshape(-1).contiguous()
+    if yd.shape[0] != N:
+        raise ValueError(f"y has {yd.shape[0]} rows, X has {N}")
+    noise_d = _lib.to_device(np.ascontiguousarray(np.asarray(noise, dtype=np.float64).reshape(-1)))
+    scale_d = None if scale is None else _lib.to_device(np.ascontiguousarray(np.asarray(scale, dtype=np.float64).reshape(-1)))
+    if noise_d.shape[0] != B or (scale_d is not None and scale_d.shape[0] != B):
+        raise ValueError(f"noise/scale must have one entry per forest ({B})")
+    pf = PackedForest(nodes3, ft)
+    Bc = int(chunk or B)
+    ws = _lib.workspace(int(lib.bark_mll_leafspace_workspace_bytes(N, int(pf.info.max_bits), pf.m, Bc)))
+    out = torch.empty(B, dtype=torch.float64, device=Xd.device)
+    info = torch.empty(B, dtype=torch.int32, device=Xd.device)
+    _lib.check(lib.bark_mll_leafspace_hip(_lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(yd),
+                                          _lib.ptr(noise_d), _lib.ptr(scale_d), flags, _lib.ptr(out), _lib.ptr(info),
+                                          _lib.ptr(ws), ws.numel(), Bc, _lib.stream_ptr()))
+    bad = info.cpu().numpy()
+    if bad.any():
+        b = int(np.flatnonzero(bad)[0])
+        raise np.linalg.LinAlgError(f"leaf-space system of forest sample {b} is not positive definite")
+    return out
+
+
 def batched_mll(forest, noise, scale, X, y, feat_types, *, include_scale: bool, include_2pi: bool,
-                return_device: bool = False, chunk: int | None = None):
+                return_device: bool = False, chunk: int | None = None, method: str = "dense"):
     """MLL of each forest sample -> (B,) float64.
 
     include_scale=False, include_2pi=True  reproduces examples/mcmc/mcmc_record_mll.py:57-74;
     include_scale=True,  include_2pi=False reproduces bark_sampler.py:153-162 (quick_inverse.mll).
+
+    method="dense" (default): leaf walk -> N x N Gram -> blocked Cholesky, the reference's computation on the GPU.
+    method="leafspace": the same value from the R x R system I + c Z'Z over the forest's leaves (exact
+    Woodbury / determinant-lemma identity, O(N R^2/64 + R^3)); opt-in, see include/bark_hip.h.
     """
     flags = (_lib.MLL_INCLUDE_SCALE if include_scale else 0) | (_lib.MLL_INCLUDE_2PI if include_2pi else 0)
     if include_scale and scale is None:
         raise ValueError("include_scale=True needs scale")
-    out, _, _ = _run(forest, noise, scale if include_scale else None, X, y, feat_types, flags, chunk=chunk)
+    if method == "leafspace":
+        out = _run_leafspace(forest, noise, scale if include_scale else None, X, y, feat_types, flags, chunk=chunk)
+    elif method == "dense":
+        out, _, _ = _run(forest, noise, scale if include_scale else None, X, y, feat_types, flags, chunk=chunk)
+    else:
+        raise ValueError(f"unknown method {method!r} (use 'dense' or 'leafspace')")
     return out if return_device else out.cpu().numpy()
 
 

@@ -172,6 +172,34 @@ def main():
                       "frac": g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         del Kg, leaves
 
+    # ---- informational only: the leaf-space evaluation of the SAME MLLs (R x R system over the leaves instead
+    # of the N x N matrix).  It does not do the Gram + Cholesky work the metric counts and is not part of `value`.
+    leaf_probe = None
+    if rank == 0:
+        lws = torch.empty(int(lib.bark_mll_leafspace_workspace_bytes(N, int(pf.info.max_bits), m, B)), dtype=torch.uint8,
+                          device=Xd.device)
+        lmll = torch.empty(B, dtype=torch.float64, device=Xd.device)
+        linfo = torch.empty(B, dtype=torch.int32, device=Xd.device)
+        l0, l1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        lreps = 5
+        for it in range(lreps + 1):
+            if it == 1:
+                l0.record()
+            _lib.check(lib.bark_mll_leafspace_hip(_lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(yd),
+                                                  _lib.ptr(noise_d), None, flags, _lib.ptr(lmll), _lib.ptr(linfo),
+                                                  _lib.ptr(lws), lws.numel(), B, stream))
+        l1.record()
+        torch.cuda.synchronize()
+        l_ms = l0.elapsed_time(l1) / lreps
+        dense_local = mll_d.cpu().numpy()
+        leaf_local = lmll.cpu().numpy()
+        leaf_probe = {"note": "exact Woodbury/determinant-lemma evaluation over the forest's leaves; NOT the benchmark "
+                              "metric (no N x N Gram, no N^3/3 Cholesky)",
+                      "leaves_per_forest_max": int(pf.info.max_bits), "ms_per_%d_evals" % B: l_ms,
+                      "evals_per_s": B / (l_ms * 1e-3),
+                      "max_rel_diff_vs_dense": float(np.max(np.abs(leaf_local - dense_local) / np.abs(dense_local)))}
+        del lws
+
     steps = args.steps
     evals = B * world * steps
     value = evals / elapsed
@@ -228,6 +256,7 @@ def main():
             "gram_stage_ms_per_step": round(per_step["gram_ms"], 3),
             "gram_kernel": gram_probe,
         },
+        "leafspace_probe": leaf_probe,
     }
 
     if rank == 0 and world == 1 and args.cpu_sample > 0:

@@ -167,6 +167,21 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, /* fore
                          void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Leaf-space MLL — the same quantity as bark_mll_batched_hip (mcmc_record_mll.py:57-74 / bark_sampler.py:153-162
+ * conventions via `flags`), computed without ever forming the N x N matrix: K = (1/m) Z Z' with Z the one-hot
+ * leaf matrix (N x R, R = info->max_bits), so
+ *   log|K_s| = N log s2 + log|I_R + c Z'Z| ,   y'K_s^-1 y = (y'y - c v'(I_R + c Z'Z)^-1 v) / s2 ,
+ *   s2 = 1e-6 + noise, c = scale / (m s2), v = Z'y .
+ * O(N R^2 / 64 + R^3) instead of O(N^3): an exact algebraic alternative (agreement with the dense path to
+ * ~1e-12 relative at noise 0.1; it loses digits as noise -> 0 through the subtraction y'y - c v'M^-1 v).
+ * It is NOT the Gram + Cholesky work the benchmark metric counts and bench.py never times it as `value`.
+ * ------------------------------------------------------------------------------------- */
+size_t bark_mll_leafspace_workspace_bytes(int64_t N, int64_t max_bits, int64_t m, int64_t Bc);
+int bark_mll_leafspace_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
+                           const double *y, const double *noise, const double *scale, int flags, double *mll_out,
+                           int32_t *info_out, void *workspace, size_t workspace_bytes, int64_t Bc, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Woodbury / determinant-lemma updates — quick_inverse.py:13-33 (the per-tree step of the sampler,
  * bark_sampler.py:233-257).  With mul = -1 if `subtract` else +1:
  *   K_out         = K_inv - K_inv U (mul I + U' K_inv U)^-1 U' K_inv          (low_rank_inv_update)

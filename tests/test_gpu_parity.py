@@ -432,6 +432,38 @@ def test_single_large_matrix_split_k_path(B):
     assert np.array_equal(again, first)
 
 
+def test_leafspace_mll_equals_dense_and_reference(B):
+    """method="leafspace" (R x R system over the leaves) against the golden MLLs, the oracle and the dense path."""
+    for name in ("g3_prior_mixed_n257", "g8_batched_mll", "g10_mcmc_posterior_forests", "g4_all_null"):
+        g = load_golden(name)
+        forest, X, y, ft = raw(B, g["forest"]), g["X"], g["y"], g["feat_types"]
+        ex = B.fit.batched_mll(forest, g["noise"], None, X, y, ft, include_scale=False, include_2pi=True, method="leafspace")
+        assert np.allclose(ex, g["mll_example"], rtol=MLL_RTOL, atol=MLL_ATOL), name
+        if "mll_sampler" in g:
+            sa = B.fit.batched_mll(forest, g["noise"], g["scale"], X, y, ft, include_scale=True, include_2pi=False,
+                                   method="leafspace")
+            assert np.allclose(sa, g["mll_sampler"], rtol=MLL_RTOL, atol=MLL_ATOL), name
+    # larger: N = 3000 (ragged), 40 forests in chunks of 16; bushy forest with 32 leaves per tree (R = 1600)
+    X, y, bounds, ft = B.syn.mixed_problem(3000, seed=31)
+    F = B.syn.sample_prior_forests(40, 50, bounds, ft, seed=31)
+    noise, scale = np.linspace(0.05, 0.3, 40), np.linspace(0.7, 1.4, 40)
+    dense = B.fit.batched_mll(F, noise, scale, X, y, ft, include_scale=True, include_2pi=True)
+    leaf = B.fit.batched_mll(F, noise, scale, X, y, ft, include_scale=True, include_2pi=True, method="leafspace", chunk=16)
+    assert np.allclose(leaf, dense, rtol=1e-10, atol=1e-8), np.abs(leaf - dense).max()
+    want = B.orc.batched_mll(F[:2], noise[:2], scale[:2], X, y, ft, include_scale=True, include_2pi=True)
+    assert np.allclose(leaf[:2], want, rtol=MLL_RTOL, atol=MLL_ATOL)
+    rng = np.random.default_rng(2)
+    Xc = rng.uniform(size=(700, 6))
+    yc = rng.standard_normal((700, 1))
+    bushy = B.syn.full_binary_forest(50, 6, 5, rng)[None]
+    got = B.fit.batched_mll(bushy, [0.1], [1.0], Xc, yc, np.full(6, 2), include_scale=True, include_2pi=True,
+                            method="leafspace")
+    want = B.orc.batched_mll(bushy, [0.1], [1.0], Xc, yc, np.full(6, 2), include_scale=True, include_2pi=True)
+    assert np.allclose(got, want, rtol=MLL_RTOL, atol=MLL_ATOL)
+    with pytest.raises(ValueError):
+        B.fit.batched_mll(bushy, [0.1], [1.0], Xc, yc, np.full(6, 2), include_scale=True, include_2pi=True, method="lu")
+
+
 def test_not_positive_definite_raises(B):
     g = load_golden("g8_batched_mll")
     forest, X, y, ft = raw(B, g["forest"]), g["X"], g["y"], g["feat_types"]
