@@ -1001,7 +1001,8 @@ struct Sweep {
             hipLaunchKernelGGL(solve_kernel, dim3(xcd_grid(n_right, bc)), dim3(THREADS), GEMM_LDS, s, p, j, n_right);
             BARK_LAUNCH_CHECK();
             if ((r = mark_on(s))) return r;
-            solve_flops += 2.0 * NB * NB * (double)NB * (double)n_right * (double)bc;
+            // 18 of the 32 (k-tile, row-tile) products per wave are executed (zero k-tiles of W_j skipped)
+            solve_flops += (18.0 / 32.0) * 2.0 * NB * NB * (double)NB * (double)n_right * (double)bc;
         }
         return BARK_OK;
     }
