@@ -48,6 +48,8 @@ int leafspace_prepare(const uint32_t *codes, int W, int npad, unsigned long long
                       const double *noise, const double *scale, int m, int bc, double *A, long ld, long bstride,
                       const double *y, int N, double *yz, double *accum, int32_t *info, hipStream_t s);
 int leafspace_sumsq(const double *y, int N, double *out, hipStream_t s);
+int leafspace_predict(const uint32_t *ccodes, int W, int cpad, int C, const double *w, const double *Minv, int R,
+                      const double *noise, const double *scale, int m, int bc, double *mu, double *var, hipStream_t s);
 int leafspace_finish(const double *accum, const double *yy, const double *noise, const double *scale, int m, int bc, int N,
                      int include_2pi, double *mll, hipStream_t s);
 
@@ -1206,19 +1208,20 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
 // Leaf-space MLL (kernels in leafspace.hip): factorises I_R + c Z'Z (R x R) instead of K_s (N x N).
 // ---------------------------------------------------------------------------------------------
 struct LeafLayout {
-    Layout L;         // the R x R sweep workspace (N := R, no candidates)
-    int64_t R, Rpad, W, npad, Q;
-    size_t off_codes, off_planes, off_yy, total;
+    Layout L;         // the R x R sweep workspace (N := R; candidates := R identity columns for the posterior)
+    int64_t R, Rpad, W, npad, Q, cpad;
+    size_t off_codes, off_planes, off_yy, off_ccodes, off_minv, off_w, total;
 };
 
-static LeafLayout make_leaf_layout(int64_t N, int64_t max_bits, int64_t m, int64_t Bc) {
+static LeafLayout make_leaf_layout(int64_t N, int64_t max_bits, int64_t m, int64_t Bc, int64_t C = 0) {
     LeafLayout g;
     g.R = max_bits;
     g.Rpad = round_up(max_bits, NB);
     g.W = (max_bits + 31) / 32;
     g.npad = round_up(N, NB);
     g.Q = g.npad / 64;
-    g.L = make_layout(max_bits, 0, m, Bc);
+    g.L = make_layout(max_bits, C > 0 ? max_bits : 0, m, Bc);
+    g.cpad = C > 0 ? round_up(C, NB) : 0;
     size_t o = g.L.total;
     g.off_codes = o;
     o = align256(o + (size_t)Bc * g.W * g.npad * sizeof(uint32_t));
@@ -1226,31 +1229,40 @@ static LeafLayout make_leaf_layout(int64_t N, int64_t max_bits, int64_t m, int64
     o = align256(o + (size_t)Bc * 32 * g.W * g.Q * sizeof(unsigned long long));
     g.off_yy = o;
     o = align256(o + 64);
+    g.off_ccodes = o;
+    o = align256(o + (size_t)Bc * g.W * g.cpad * sizeof(uint32_t));
+    g.off_minv = o;
+    if (C > 0) o = align256(o + (size_t)Bc * max_bits * max_bits * sizeof(double));
+    g.off_w = o;
+    if (C > 0) o = align256(o + (size_t)Bc * max_bits * sizeof(double));
     g.total = o;
     return g;
 }
 
-size_t bark_mll_leafspace_workspace_bytes(int64_t N, int64_t max_bits, int64_t m, int64_t Bc) {
-    if (N < 1 || max_bits < 1 || m < 1 || Bc < 1) return 0;
-    return make_leaf_layout(N, max_bits, m, Bc).total;
+size_t bark_mll_leafspace_workspace_bytes(int64_t N, int64_t max_bits, int64_t m, int64_t Bc, int64_t C) {
+    if (N < 1 || max_bits < 1 || m < 1 || Bc < 1 || C < 0) return 0;
+    return make_leaf_layout(N, max_bits, m, Bc, C).total;
 }
 
 int bark_mll_leafspace_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
-                           const double *y, const double *noise, const double *scale, int flags, double *mll_out,
-                           int32_t *info_out, void *workspace, size_t workspace_bytes, int64_t Bc, void *stream_) {
+                           const double *y, const double *noise, const double *scale, int flags, const double *cand,
+                           int64_t C, double *mll_out, double *mu_out, double *var_out, int32_t *info_out,
+                           void *workspace, size_t workspace_bytes, int64_t Bc, void *stream_) {
     error_buffer()[0] = 0;
     if (!packed || !info || !X || !y || !noise || !mll_out || !info_out || !workspace)
         return fail(BARK_ERR_ARG, "bark_mll_leafspace_hip: null argument");
     const int64_t B = info->B, m = info->m;
-    if (N < 1 || d < 1 || B < 1 || Bc < 1 || N > (1 << 24))
-        return fail(BARK_ERR_ARG, "bark_mll_leafspace_hip: bad shape N=%lld d=%lld B=%lld Bc=%lld", (long long)N, (long long)d,
-                    (long long)B, (long long)Bc);
+    if (N < 1 || d < 1 || B < 1 || Bc < 1 || C < 0 || N > (1 << 24) || C > (1 << 24))
+        return fail(BARK_ERR_ARG, "bark_mll_leafspace_hip: bad shape N=%lld d=%lld B=%lld Bc=%lld C=%lld", (long long)N,
+                    (long long)d, (long long)B, (long long)Bc, (long long)C);
+    if (C > 0 && (!cand || !mu_out || !var_out || !scale || !(flags & BARK_MLL_INCLUDE_SCALE)))
+        return fail(BARK_ERR_ARG, "leaf-space posterior needs cand, mu_out, var_out, scale and BARK_MLL_INCLUDE_SCALE");
     if ((flags & BARK_MLL_INCLUDE_SCALE) && !scale) return fail(BARK_ERR_ARG, "BARK_MLL_INCLUDE_SCALE without scale");
     if (flags & BARK_MLL_RHS_IDENTITY) return fail(BARK_ERR_ARG, "leaf-space path computes the MLL only");
     if (info->max_bits > 8192) return fail(BARK_ERR_ARG, "leaf-space path supports at most 8192 leaves per forest");
     if (Bc > B) Bc = B;
     if (Bc > 65535) Bc = 65535;
-    const LeafLayout g = make_leaf_layout(N, info->max_bits, m, Bc);
+    const LeafLayout g = make_leaf_layout(N, info->max_bits, m, Bc, C);
     if (workspace_bytes < g.total) return fail(BARK_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", workspace_bytes, g.total);
     if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(BARK_ERR_ARG, "workspace must be 256-byte aligned");
     int rc = set_lds_limits();
@@ -1262,9 +1274,11 @@ int bark_mll_leafspace_hip(const void *packed, const bark_pack_info *info, const
     if (overlap_env && (rc = get_device_res(&res, (size_t)2 * nrb))) return rc;
 
     char *ws = static_cast<char *>(workspace);
+    const int ncb = (int)(g.L.ncols / NB);  // posterior: R identity columns appended (M^-1 and w = M^-1 v)
     Sweep sw;
     sw.res = res;
-    sw.nrb = sw.ncb = nrb;
+    sw.nrb = nrb;
+    sw.ncb = ncb;
     sw.fused = false;
     sw.splitk = g.L.splitk;
     sw.slabs = reinterpret_cast<double *>(ws + g.L.off_slab);
@@ -1277,7 +1291,8 @@ int bark_mll_leafspace_hip(const void *packed, const bark_pack_info *info, const
     p.W = reinterpret_cast<double *>(ws + g.L.off_W);
     p.yz = reinterpret_cast<double *>(ws + g.L.off_yz);
     p.accum = reinterpret_cast<double *>(ws + g.L.off_acc);
-    p.nrb = p.ncb = nrb;
+    p.nrb = nrb;
+    p.ncb = ncb;
     p.leafx = nullptr;
     p.scale = p.shift = p.noise = nullptr;
     p.nW = 0;
@@ -1286,6 +1301,9 @@ int bark_mll_leafspace_hip(const void *packed, const bark_pack_info *info, const
     uint32_t *codes = reinterpret_cast<uint32_t *>(ws + g.off_codes);
     unsigned long long *planes = reinterpret_cast<unsigned long long *>(ws + g.off_planes);
     double *yy = reinterpret_cast<double *>(ws + g.off_yy);
+    uint32_t *ccodes = reinterpret_cast<uint32_t *>(ws + g.off_ccodes);
+    double *Minv = reinterpret_cast<double *>(ws + g.off_minv);
+    double *wvec = reinterpret_cast<double *>(ws + g.off_w);
     const bool use_scale = (flags & BARK_MLL_INCLUDE_SCALE) != 0;
 
     if ((rc = leafspace_sumsq(y, (int)N, yy, caller))) return rc;
@@ -1301,11 +1319,31 @@ int bark_mll_leafspace_hip(const void *packed, const bark_pack_info *info, const
                                use_scale ? scale + c0 : nullptr, (int)m, (int)bc, p.A, p.ld, p.bstride, y, (int)N, p.yz,
                                p.accum, p.info, caller);
         if (rc) return rc;
+        if (C > 0) {  // right-hand side block := I_R, so the sweep also yields V = U^-T
+            dim3 gi((unsigned)((g.L.cpad + 255) / 256), (unsigned)g.L.npad, (unsigned)bc);
+            hipLaunchKernelGGL(identity_rhs_kernel, gi, dim3(256), 0, caller, p, (int)g.R, (int)g.L.cpad);
+            BARK_LAUNCH_CHECK();
+        }
         for (int j = 0; j < nrb; ++j)
             if ((rc = sw.step(j))) return rc;
         rc = leafspace_finish(p.accum, yy, noise + c0, use_scale ? scale + c0 : nullptr, (int)m, (int)bc, (int)N,
                               (flags & BARK_MLL_INCLUDE_2PI) ? 1 : 0, mll_out + c0, caller);
         if (rc) return rc;
+        if (C > 0) {
+            // w = M^-1 v = V'z and M^-1 = V'V (the same kernels the dense posterior / inverse export use)
+            const int R = (int)g.R;
+            hipLaunchKernelGGL(predict_reduce_kernel, dim3((unsigned)((R + 255) / 256), (unsigned)bc), dim3(256), 0, caller, p, R,
+                               R, (const double *)nullptr, wvec, (double *)nullptr);
+            BARK_LAUNCH_CHECK();
+            const int nct = (int)(g.L.cpad / NB);
+            hipLaunchKernelGGL(vtv_kernel, dim3(xcd_grid(nct * nct, (int)bc)), dim3(THREADS), GEMM_LDS, caller, p, nct, R,
+                               (const double *)nullptr, 1.0, 1, Minv);
+            BARK_LAUNCH_CHECK();
+            if ((rc = walk_one_hot(packed_c, &sub, cand, C, d, (int)g.W, ccodes, caller))) return rc;
+            rc = leafspace_predict(ccodes, (int)g.W, (int)g.cpad, (int)C, wvec, Minv, R, noise + c0, scale + c0, (int)m,
+                                   (int)bc, mu_out + (size_t)c0 * C, var_out + (size_t)c0 * C, caller);
+            if (rc) return rc;
+        }
     }
     return BARK_OK;
 }

@@ -133,6 +133,56 @@ __global__ void finish_leafspace_kernel(const double *__restrict__ accum, const 
     mll[b] = -0.5 * v;
 }
 
+// Posterior at the candidates from the leaf-space quantities (derivation in include/bark_hip.h):
+//     mu_c  = coef * sum_{a in L(c)} w[a]                    w = M^-1 v
+//     var_c = (scale / m) * sum_{a, b in L(c)} Minv[a][b]     L(c) = the m leaves candidate c reaches
+// One thread per (candidate, forest); its leaf positions are decoded from the candidate's one-hot code.
+constexpr int LP_MAX_TREES = 64;
+__global__ __launch_bounds__(128) void leaf_predict_kernel(const uint32_t *__restrict__ ccodes, int W, int cpad, int C,
+                                                           const double *__restrict__ w, const double *__restrict__ Minv,
+                                                           int R, const double *__restrict__ noise,
+                                                           const double *__restrict__ scale, int m,
+                                                           double *__restrict__ mu, double *__restrict__ var) {
+    const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    unsigned short leaf[LP_MAX_TREES];
+    int n = 0;
+    for (int wd = 0; wd < W; ++wd) {
+        uint32_t bits = ccodes[((size_t)b * W + wd) * cpad + c];
+        while (bits && n < LP_MAX_TREES) {
+            const int k = __ffs(bits) - 1;
+            bits &= bits - 1;
+            leaf[n++] = (unsigned short)(32 * wd + k);
+        }
+    }
+    const double *wb = w + (size_t)b * R;
+    const double *Mb = Minv + (size_t)b * R * R;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < n; ++i) {
+        s1 += wb[leaf[i]];
+        const double *row = Mb + (size_t)leaf[i] * R;
+        double r = 0.0;
+        for (int k = 0; k < n; ++k) r += row[leaf[k]];
+        s2 += r;
+    }
+    const double sigma2 = 1e-6 + noise[b];
+    const double sc = scale[b];
+    mu[(size_t)b * C + c] = sc / ((double)m * sigma2) * s1;
+    var[(size_t)b * C + c] = sc / (double)m * s2;
+}
+
+}  // namespace
+
+int leafspace_predict(const uint32_t *ccodes, int W, int cpad, int C, const double *w, const double *Minv, int R,
+                      const double *noise, const double *scale, int m, int bc, double *mu, double *var, hipStream_t s) {
+    if (m > LP_MAX_TREES) return fail(BARK_ERR_ARG, "leaf-space posterior supports at most %d trees", LP_MAX_TREES);
+    hipLaunchKernelGGL(leaf_predict_kernel, dim3((unsigned)((C + 127) / 128), (unsigned)bc), dim3(128), 0, s, ccodes, W, cpad, C, w,
+                       Minv, R, noise, scale, m, mu, var);
+    BARK_LAUNCH_CHECK();
+    return BARK_OK;
+}
+
+namespace {
 }  // namespace
 
 // launchers used by the entry point in chol.hip -----------------------------------------------------------

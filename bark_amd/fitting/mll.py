@@ -162,8 +162,9 @@ def batched_kernel_inverse(forest, noise, scale, X, y, feat_types, *, no_null: b
     return K_inv.cpu().numpy(), K_inv_y.cpu().numpy(), logdet.cpu().numpy()
 
 
-def _run_leafspace(forest, noise, scale, X, y, feat_types, flags, chunk=None):
-    """Leaf-space evaluation (bark_mll_leafspace_hip): R x R system instead of N x N."""
+def _run_leafspace(forest, noise, scale, X, y, feat_types, flags, chunk=None, cand=None):
+    """Leaf-space evaluation (bark_mll_leafspace_hip): R x R system instead of N x N.
+    Returns the (B,) MLL tensor, or (mll, mu, var) when candidates are given."""
     import torch
 
     lib = _lib.lib()
@@ -182,19 +183,28 @@ def _run_leafspace(forest, noise, scale, X, y, feat_types, flags, chunk=None):
     scale_d = None if scale is None else _lib.to_device(np.ascontiguousarray(np.asarray(scale, dtype=np.float64).reshape(-1)))
     if noise_d.shape[0] != B or (scale_d is not None and scale_d.shape[0] != B):
         raise ValueError(f"noise/scale must have one entry per forest ({B})")
+    C = 0
+    cand_d = mu = var = None
+    if cand is not None:
+        cand_d, _ = _points(cand, ft.shape[0])
+        _check_categorical(cand_d, ft)
+        C = cand_d.shape[0]
+        mu = torch.empty((B, C), dtype=torch.float64, device=Xd.device)
+        var = torch.empty((B, C), dtype=torch.float64, device=Xd.device)
     pf = PackedForest(nodes3, ft)
     Bc = int(chunk or B)
-    ws = _lib.workspace(int(lib.bark_mll_leafspace_workspace_bytes(N, int(pf.info.max_bits), pf.m, Bc)))
+    ws = _lib.workspace(int(lib.bark_mll_leafspace_workspace_bytes(N, int(pf.info.max_bits), pf.m, Bc, C)))
     out = torch.empty(B, dtype=torch.float64, device=Xd.device)
     info = torch.empty(B, dtype=torch.int32, device=Xd.device)
     _lib.check(lib.bark_mll_leafspace_hip(_lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(yd),
-                                          _lib.ptr(noise_d), _lib.ptr(scale_d), flags, _lib.ptr(out), _lib.ptr(info),
+                                          _lib.ptr(noise_d), _lib.ptr(scale_d), flags, _lib.ptr(cand_d), C,
+                                          _lib.ptr(out), _lib.ptr(mu), _lib.ptr(var), _lib.ptr(info),
                                           _lib.ptr(ws), ws.numel(), Bc, _lib.stream_ptr()))
     bad = info.cpu().numpy()
     if bad.any():
         b = int(np.flatnonzero(bad)[0])
         raise np.linalg.LinAlgError(f"leaf-space system of forest sample {b} is not positive definite")
-    return out
+    return out if cand is None else (out, mu, var)
 
 
 def batched_mll(forest, noise, scale, X, y, feat_types, *, include_scale: bool, include_2pi: bool,

@@ -13,19 +13,29 @@ from __future__ import annotations
 import numpy as np
 
 from .. import _lib
-from ..fitting.mll import _feat_types_of, _run
+from ..fitting.mll import _feat_types_of, _run, _run_leafspace
 from ..forest import _is_torch
 
 
-def forest_predict(model, data, candidates, domain, diag: bool = True):
-    """tree_gps.py:80-113 -> (mu (B, C), var (B, C) or (B, C, C) if not diag); `domain` may be feat_types."""
+def forest_predict(model, data, candidates, domain, diag: bool = True, method: str = "dense"):
+    """tree_gps.py:80-113 -> (mu (B, C), var (B, C) or (B, C, C) if not diag); `domain` may be feat_types.
+
+    method="dense" (default) follows the reference's computation (Gram, factorisation of the N x N matrix);
+    method="leafspace" (diag only, <= 64 trees) evaluates the same posterior in closed form over the forest's
+    leaves: mu = c sum_{a in L(x)} w_a, var = (scale/m) sum_{a,b in L(x)} (M^-1)_ab — see include/bark_hip.h."""
     forest, noise, scale = model
     train_x, train_y = data
     forest = np.asarray(forest)
     noise = np.asarray(noise, dtype=np.float64).reshape(-1)   # tree_gps.py:88-90 flatten
     scale = np.asarray(scale, dtype=np.float64).reshape(-1)
     flags = _lib.MLL_INCLUDE_SCALE
-    if diag:
+    if method == "leafspace":
+        if not diag:
+            raise ValueError("method='leafspace' provides the diagonal posterior only")
+        _, mu, var = _run_leafspace(forest, noise, scale, train_x, train_y, _feat_types_of(domain), flags, cand=candidates)
+    elif method != "dense":
+        raise ValueError(f"unknown method {method!r} (use 'dense' or 'leafspace')")
+    elif diag:
         _, mu, var = _run(forest, noise, scale, train_x, train_y, _feat_types_of(domain), flags, cand=candidates)
     else:  # tree_gps.py:108: full (B, C, C) covariance scale - K_xX K^-1 K_Xx (one extra MFMA V'V product)
         _, mu, _, var = _run(forest, noise, scale, train_x, train_y, _feat_types_of(domain), flags, cand=candidates,

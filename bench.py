@@ -176,7 +176,7 @@ def main():
     # of the N x N matrix).  It does not do the Gram + Cholesky work the metric counts and is not part of `value`.
     leaf_probe = None
     if rank == 0:
-        lws = torch.empty(int(lib.bark_mll_leafspace_workspace_bytes(N, int(pf.info.max_bits), m, B)), dtype=torch.uint8,
+        lws = torch.empty(int(lib.bark_mll_leafspace_workspace_bytes(N, int(pf.info.max_bits), m, B, 0)), dtype=torch.uint8,
                           device=Xd.device)
         lmll = torch.empty(B, dtype=torch.float64, device=Xd.device)
         linfo = torch.empty(B, dtype=torch.int32, device=Xd.device)
@@ -186,8 +186,8 @@ def main():
             if it == 1:
                 l0.record()
             _lib.check(lib.bark_mll_leafspace_hip(_lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(yd),
-                                                  _lib.ptr(noise_d), None, flags, _lib.ptr(lmll), _lib.ptr(linfo),
-                                                  _lib.ptr(lws), lws.numel(), B, stream))
+                                                  _lib.ptr(noise_d), None, flags, None, 0, _lib.ptr(lmll), None, None,
+                                                  _lib.ptr(linfo), _lib.ptr(lws), lws.numel(), B, stream))
         l1.record()
         torch.cuda.synchronize()
         l_ms = l0.elapsed_time(l1) / lreps

@@ -175,11 +175,16 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, /* fore
  * O(N R^2 / 64 + R^3) instead of O(N^3): an exact algebraic alternative (agreement with the dense path to
  * ~1e-12 relative at noise 0.1; it loses digits as noise -> 0 through the subtraction y'y - c v'M^-1 v).
  * It is NOT the Gram + Cholesky work the benchmark metric counts and bench.py never times it as `value`.
+ * Posterior (tree_gps.py:80-113, diagonal) in the same leaf space, with M = I_R + c Z'Z, w = M^-1 v and L(x) the m
+ * leaves a candidate x reaches (Z'K_s^-1 Z = (m/scale)(I - M^-1)):
+ *   mu(x) = c * sum_{a in L(x)} w_a ,    var(x) = (scale/m) * sum_{a,b in L(x)} (M^-1)_ab .
+ * Pass C candidates (+ mu_out, var_out (B, C), scale, BARK_MLL_INCLUDE_SCALE); at most 64 trees.
  * ------------------------------------------------------------------------------------- */
-size_t bark_mll_leafspace_workspace_bytes(int64_t N, int64_t max_bits, int64_t m, int64_t Bc);
+size_t bark_mll_leafspace_workspace_bytes(int64_t N, int64_t max_bits, int64_t m, int64_t Bc, int64_t C);
 int bark_mll_leafspace_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
-                           const double *y, const double *noise, const double *scale, int flags, double *mll_out,
-                           int32_t *info_out, void *workspace, size_t workspace_bytes, int64_t Bc, void *stream);
+                           const double *y, const double *noise, const double *scale, int flags, const double *cand,
+                           int64_t C, double *mll_out, double *mu_out, double *var_out, int32_t *info_out,
+                           void *workspace, size_t workspace_bytes, int64_t Bc, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Woodbury / determinant-lemma updates — quick_inverse.py:13-33 (the per-tree step of the sampler,

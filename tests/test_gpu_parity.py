@@ -462,6 +462,15 @@ def test_leafspace_mll_equals_dense_and_reference(B):
     assert np.allclose(got, want, rtol=MLL_RTOL, atol=MLL_ATOL)
     with pytest.raises(ValueError):
         B.fit.batched_mll(bushy, [0.1], [1.0], Xc, yc, np.full(6, 2), include_scale=True, include_2pi=True, method="lu")
+    # posterior in leaf space: golden (reference arithmetic), then a larger mixed problem against the dense path
+    g = load_golden("g6_predict")
+    model = (raw(B, g["forest"]), g["noise"], g["scale"])
+    mu, var = B.tk.forest_predict(model, (g["X"], g["y"]), g["cand"], g["feat_types"], method="leafspace")
+    assert np.allclose(mu, g["mu"], rtol=1e-9, atol=1e-9) and np.allclose(var, g["var"], rtol=1e-9, atol=1e-9)
+    cand, _, _, _ = B.syn.mixed_problem(1000, seed=32)
+    mu_d, var_d = B.tk.forest_predict((F[:5], noise[:5], scale[:5]), (X, y), cand, ft)
+    mu_l, var_l = B.tk.forest_predict((F[:5], noise[:5], scale[:5]), (X, y), cand, ft, method="leafspace")
+    assert np.allclose(mu_l, mu_d, rtol=1e-9, atol=1e-10) and np.allclose(var_l, var_d, rtol=1e-8, atol=1e-10)
 
 
 def test_not_positive_definite_raises(B):
