@@ -5,28 +5,285 @@
 //
 // with mul = -1 for subtract.  In the sampler U is N x r (r = #leaves of one tree, single digits), so
 // the work is two streaming passes over the N x N matrix and r x r algebra in between:
-//   1. skinny_kernel   Y = K_inv U            one wave per row, 64-wide coalesced reads   (HBM read, 8 N^2 B)
-//   2. small_kernel    G = U'Y, den = mul I + G, LU with partial pivoting -> den^-1, log|det|;  M = Y den^-1
+//   1. skinny_kernel   Y = K_inv U, plus every workgroup's share of G = U'Y (and Y'y)       (HBM read, 8 N^2 B)
+//      colsum_kernel + colsum_finish_kernel: the same for symmetric K_inv (and K_inv'U in general), column form
+//   2. small_kernel    G = sum of shares, den = mul I + G, LU with partial pivoting -> den^-1, log|det|
 //                      (one workgroup; r <= 64)
-//   3. rank_update_kernel   out = K_inv - M Y'   64x64 tiles, M/Y strips in LDS          (HBM read+write, 16 N^2 B)
+//   3. left_factor_kernel   M = Y den^-1                                                   (N r, tiny)
+//   4. rank_update_kernel   out = K_inv - M Y'   64x64 tiles, M/Y strips in LDS          (HBM read+write, 16 N^2 B)
 // K_inv is treated as a general (not necessarily symmetric) matrix exactly as the reference's formula does:
 // the right factor is U' K_inv, computed as its own pass when `symmetric == 0`.
 #include "common.h"
 
 namespace bark {
+int walk_one_hot(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d, int words,
+                 uint32_t *out, hipStream_t stream);  // traverse.hip
+
 namespace {
 
 constexpr int LR_MAX = 64;  // max rank r
 constexpr int LR_THREADS = 256;
+#ifndef SK_RW_SMALL
+#define SK_RW_SMALL 2  // rows per wave for r <= 16
+#endif
+#ifndef SK_KL_SMALL
+#define SK_KL_SMALL 1  // 128-column groups per chunk for r <= 16
+#endif
 
-// out[i][c] = sum_k K[i][k] * U[k][c]      (TRANS == 0)   one wave per output row i
-// out[i][c] = sum_k K[k][i] * U[k][c]      (TRANS == 1)   (= (U' K)' : column i of K), lanes stride rows
-template <int TRANS, int RT>  // RT: compile-time bound on r (registers)
+typedef double lr_double2 __attribute__((ext_vector_type(2)));
+
+// Y = K U for a skinny U (N x r), K row-major N x N, streamed once at HBM rate.
+// A workgroup owns 4*RW rows (RW per wave); a lane owns KL column pairs of every KC = 128*KL column chunk
+// (16-byte loads when N is even), the next chunk's K values are in flight while the current one is
+// multiplied, and the chunk of U (KC x r) is double-buffered in LDS and shared by all rows.
+// Epilogue: besides Y the workgroup writes its share of G = U'Y (r x r) and, with `y`, of v = Y'y (r) to
+// `partial[block][r*r + r]`; reduce_shares_kernel adds the shares in block order, so results are reproducible.
+template <int RT, bool VEC, int RW, int KL>  // RT: compile-time bound on r; VEC: N even
 __global__ __launch_bounds__(LR_THREADS) void skinny_kernel(const double *__restrict__ K, const double *__restrict__ U,
-                                                            int N, int r, double *__restrict__ out) {
+                                                            int N, int r, double *__restrict__ out,
+                                                            const double *__restrict__ y,
+                                                            double *__restrict__ partial) {
+    constexpr int ROWS = 4 * RW, KC = 128 * KL, KCP = KC + 2;  // padded: the transposing stores spread over banks
+    extern __shared__ __attribute__((aligned(16))) double us[];  // 2 x [r][KCP]: U chunk transposed, so a lane's
+                                                                 // two k values are one conflict-free 16-byte read
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = blockIdx.x * ROWS;
+    const double *Krow[RW];
+#pragma unroll
+    for (int q = 0; q < RW; ++q) Krow[q] = K + (size_t)min(row0 + RW * wave + q, N - 1) * N;  // clamped, not stored
+    double acc[RW][RT];
+#pragma unroll
+    for (int q = 0; q < RW; ++q)
+#pragma unroll
+        for (int c = 0; c < RT; ++c) acc[q][c] = 0.0;
+
+    auto load2 = [&](const double *row, int k) -> lr_double2 {
+        lr_double2 v = {0.0, 0.0};
+        if (VEC) {
+            if (k < N) v = *reinterpret_cast<const lr_double2 *>(row + k);  // N even: k + 1 < N as well
+        } else {
+            if (k < N) v.x = row[k];
+            if (k + 1 < N) v.y = row[k + 1];
+        }
+        return v;
+    };
+    auto stage = [&](int buf, int k0) {
+        double *dst = us + (size_t)buf * r * KCP;
+        const int rows = min(KC, N - k0);
+        const double *src = U + (size_t)k0 * r;  // rows k0.. are contiguous in U: coalesced reads
+        for (int e = threadIdx.x; e < KC * r; e += LR_THREADS) {
+            const int k = e / r, c = e - k * r;
+            dst[c * KCP + k] = (e < rows * r) ? src[e] : 0.0;
+        }
+    };
+
+    // Workgroups start at different chunks and wrap around: with a power-of-two row pitch, lock-step reads of
+    // the same column range from every row would all land on the same few HBM channels.
+    const int chunks = (N + KC - 1) / KC;
+    const int first = (int)(blockIdx.x % (unsigned)chunks);
+    stage(0, first * KC);
+    lr_double2 kv[RW][KL], nx[RW][KL];
+#pragma unroll
+    for (int q = 0; q < RW; ++q)
+#pragma unroll
+        for (int h = 0; h < KL; ++h) kv[q][h] = load2(Krow[q], first * KC + 128 * h + 2 * lane);
+    __syncthreads();
+    for (int ch = 0; ch < chunks; ++ch) {
+        int next_chunk = first + ch + 1;
+        if (next_chunk >= chunks) next_chunk -= chunks;
+        const int k_next = next_chunk * KC;
+        if (ch + 1 < chunks) {
+#pragma unroll
+            for (int q = 0; q < RW; ++q)
+#pragma unroll
+                for (int h = 0; h < KL; ++h) nx[q][h] = load2(Krow[q], k_next + 128 * h + 2 * lane);
+            stage((ch + 1) & 1, k_next);
+        }
+#pragma unroll
+        for (int h = 0; h < KL; ++h) {
+            const double *u0 = us + (size_t)(ch & 1) * r * KCP + 128 * h + 2 * lane;
+#pragma unroll
+            for (int c = 0; c < RT; ++c)
+                if (c < r) {
+                    const lr_double2 u = *reinterpret_cast<const lr_double2 *>(u0 + c * KCP);
+#pragma unroll
+                    for (int q = 0; q < RW; ++q) acc[q][c] = fma(kv[q][h].y, u.y, fma(kv[q][h].x, u.x, acc[q][c]));
+                }
+        }
+        if (ch + 1 < chunks) {
+#pragma unroll
+            for (int q = 0; q < RW; ++q)
+#pragma unroll
+                for (int h = 0; h < KL; ++h) kv[q][h] = nx[q][h];
+        }
+        __syncthreads();  // the other buffer is complete, this one may be overwritten next iteration
+    }
+    // wave reduction; every lane ends with the full sums
+#pragma unroll
+    for (int q = 0; q < RW; ++q)
+#pragma unroll
+        for (int c = 0; c < RT; ++c)
+            if (c < r) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) acc[q][c] += __shfl_xor(acc[q][c], off);
+            }
+    // Y rows -> global and LDS (for the r x r share); LDS is free again after the loop's last barrier
+    double *ys = us;                 // [ROWS][r]
+    double *ur = us + ROWS * r;      // [ROWS][r] rows of U
+    double *yv = us + 2 * ROWS * r;  // [ROWS]    entries of y
+#pragma unroll
+    for (int q = 0; q < RW; ++q) {
+        const int lrow = RW * wave + q, row = row0 + lrow;
+#pragma unroll
+        for (int c = 0; c < RT; ++c)
+            if (c < r && lane == (c & 63)) {
+                ys[lrow * r + c] = row < N ? acc[q][c] : 0.0;
+                if (row < N) out[(size_t)row * r + c] = acc[q][c];
+            }
+    }
+    if (partial) {
+        for (int e = threadIdx.x; e < ROWS * r; e += LR_THREADS) {
+            const int q = e / r;
+            ur[e] = (row0 + q < N) ? U[(size_t)row0 * r + e] : 0.0;
+        }
+        if (threadIdx.x < ROWS) yv[threadIdx.x] = (y && row0 + threadIdx.x < N) ? y[row0 + threadIdx.x] : 0.0;
+        __syncthreads();
+        double *dst = partial + (size_t)blockIdx.x * (r * r + r);
+        for (int e = threadIdx.x; e < r * r + r; e += LR_THREADS) {
+            double g = 0.0;
+            if (e < r * r) {
+                const int a = e / r, b = e - a * r;
+#pragma unroll
+                for (int q = 0; q < ROWS; ++q) g = fma(ur[q * r + a], ys[q * r + b], g);
+            } else {
+                const int b = e - r * r;
+#pragma unroll
+                for (int q = 0; q < ROWS; ++q) g = fma(yv[q], ys[q * r + b], g);
+            }
+            dst[e] = g;
+        }
+    }
+}
+
+// Column form for a symmetric K (and K'U for any K):  P[seg][i][c] = sum_{k in segment} K[k][i] * U[k][c].
+// A lane owns two adjacent output indices i, so a wave reads 1 KiB of row k per step; U[k][.] is the same for
+// the whole wave (scalar loads), nothing goes through LDS inside the loop, there is no barrier and no cross-lane
+// reduction, and CS_UNROLL rows are in flight per wave.  grid = (ceil(N/128), ceil(N/seg_rows)); the four waves of a
+// workgroup take interleaved rows of the segment and are summed through LDS in wave order.  N must be even.
+constexpr int CS_UNROLL = 4;     // rows in flight per wave (measured: 4 > 8 > 16 at N = 4096)
+constexpr int CS_FIN_ROWS = 16;  // rows of Y per colsum_finish_kernel workgroup
+
+// rows of K per workgroup: 128 up to N = 4096 (1024 workgroups there; fewer, longer ones measured slower), growing
+// with N so that at most 32 segment partials are written and summed
+inline int colsum_segment(int64_t N) { return 128 * (int)((N + 4095) / 4096); }
+
+template <int RT>
+__global__ __launch_bounds__(LR_THREADS) void colsum_kernel(const double *__restrict__ K, const double *__restrict__ U,
+                                                            int N, int r, int seg_rows, double *__restrict__ P) {
+    extern __shared__ __attribute__((aligned(16))) double red[];  // [4][128][r]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = blockIdx.x * 128 + 2 * lane;
+    const int k_begin = blockIdx.y * seg_rows, k_end = min(N, k_begin + seg_rows);
+    const bool live = i < N;  // N even: i + 1 < N as well
+    double ax[RT], ay[RT];
+#pragma unroll
+    for (int c = 0; c < RT; ++c) ax[c] = ay[c] = 0.0;
+    for (int k0 = k_begin + wave * CS_UNROLL; k0 < k_end; k0 += 4 * CS_UNROLL) {
+        lr_double2 kv[CS_UNROLL];
+#pragma unroll
+        for (int u = 0; u < CS_UNROLL; ++u) {
+            kv[u] = lr_double2{0.0, 0.0};
+            if (live && k0 + u < k_end) kv[u] = *reinterpret_cast<const lr_double2 *>(K + (size_t)(k0 + u) * N + i);
+        }
+#pragma unroll
+        for (int u = 0; u < CS_UNROLL; ++u) {
+            const double *urow = U + (size_t)min(k0 + u, N - 1) * r;  // wave-uniform address: scalar loads
+#pragma unroll
+            for (int c = 0; c < RT; ++c)
+                if (c < r) {
+                    const double uv = urow[c];
+                    ax[c] = fma(kv[u].x, uv, ax[c]);
+                    ay[c] = fma(kv[u].y, uv, ay[c]);
+                }
+        }
+    }
+    // the four waves hold disjoint row subsets: sum them in wave order
+#pragma unroll
+    for (int c = 0; c < RT; ++c)
+        if (c < r) {
+            red[((size_t)wave * 128 + 2 * lane) * r + c] = ax[c];
+            red[((size_t)wave * 128 + 2 * lane + 1) * r + c] = ay[c];
+        }
+    __syncthreads();
+    double *dst = P + ((size_t)blockIdx.y * N + (size_t)blockIdx.x * 128) * r;
+    const int cols = min(128, N - blockIdx.x * 128);
+    for (int e = threadIdx.x; e < cols * r; e += LR_THREADS)
+        dst[e] = ((red[e] + red[128 * r + e]) + red[2 * 128 * r + e]) + red[3 * 128 * r + e];
+}
+
+// Y[i][c] = sum over segments of P[seg][i][c] (fixed order); with `partial`, also this block of CS_FIN_ROWS rows'
+// share of G = U'Y and v = Y'y, in the layout reduce_shares_kernel expects.
+__global__ __launch_bounds__(LR_THREADS) void colsum_finish_kernel(const double *__restrict__ P, int segs,
+                                                                   const double *__restrict__ U, int N, int r,
+                                                                   double *__restrict__ Y, const double *__restrict__ y,
+                                                                   double *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];  // ys[ROWS][r] | ur[ROWS][r] | yv[ROWS]
+    constexpr int ROWS = CS_FIN_ROWS;
+    double *ys = sh, *ur = sh + ROWS * r, *yv = sh + 2 * ROWS * r;
+    const int row0 = blockIdx.x * ROWS;
+    const int rows = min(ROWS, N - row0);
+    for (int e = threadIdx.x; e < ROWS * r; e += LR_THREADS) {
+        double v = 0.0, uv = 0.0;
+        if (e < rows * r) {
+            const size_t at = (size_t)row0 * r + e;
+#pragma unroll 8
+            for (int sg = 0; sg < segs; ++sg) v += P[(size_t)sg * N * r + at];
+            Y[at] = v;
+            if (partial) uv = U[at];
+        }
+        ys[e] = v;
+        ur[e] = uv;
+    }
+    if (!partial) return;
+    if (threadIdx.x < ROWS) yv[threadIdx.x] = (y && threadIdx.x < rows) ? y[row0 + threadIdx.x] : 0.0;
+    __syncthreads();
+    double *dst = partial + (size_t)blockIdx.x * (r * r + r);
+    for (int e = threadIdx.x; e < r * r + r; e += LR_THREADS) {
+        double g = 0.0;
+        if (e < r * r) {
+            const int a = e / r, b = e - a * r;
+#pragma unroll
+            for (int q = 0; q < ROWS; ++q) g = fma(ur[q * r + a], ys[q * r + b], g);
+        } else {
+            const int b = e - r * r;
+#pragma unroll
+            for (int q = 0; q < ROWS; ++q) g = fma(yv[q], ys[q * r + b], g);
+        }
+        dst[e] = g;
+    }
+}
+
+// sums[e] = sum over blocks of partial[block][e], one wave per entry, fixed order
+__global__ __launch_bounds__(LR_THREADS) void reduce_shares_kernel(const double *__restrict__ partial, int nblocks,
+                                                                   int per, double *__restrict__ sums) {
+    const int e = blockIdx.x * (LR_THREADS / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= per) return;
+    double g = 0.0;
+    for (int blk = lane; blk < nblocks; blk += 64) g += partial[(size_t)blk * per + e];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) g += __shfl_xor(g, off);
+    if (lane == 0) sums[e] = g;
+}
+
+// out[i][c] = sum_k K[k][i] * U[k][c]  (= (U'K)': column i of K) — only for a K_inv not known to be symmetric.
+// One wave per output index i, lanes stride k.
+template <int RT>
+__global__ __launch_bounds__(LR_THREADS) void skinny_t_kernel(const double *__restrict__ K, const double *__restrict__ U,
+                                                              int N, int r, double *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) double us[];  // [64][r] chunk of U
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * (LR_THREADS / 64) + wave;  // output row of this wave
+    const int i = blockIdx.x * (LR_THREADS / 64) + wave;
     double s[RT];
 #pragma unroll
     for (int c = 0; c < RT; ++c) s[c] = 0.0;
@@ -39,7 +296,7 @@ __global__ __launch_bounds__(LR_THREADS) void skinny_kernel(const double *__rest
         __syncthreads();
         const int k = k0 + lane;
         double kv = 0.0;
-        if (i < N && k < N) kv = TRANS ? K[(size_t)k * N + i] : K[(size_t)i * N + k];
+        if (i < N && k < N) kv = K[(size_t)k * N + i];
 #pragma unroll
         for (int c = 0; c < RT; ++c)
             if (c < r) s[c] = fma(kv, us[lane * r + c], s[c]);
@@ -55,27 +312,26 @@ __global__ __launch_bounds__(LR_THREADS) void skinny_kernel(const double *__rest
     }
 }
 
-// One workgroup: G = U'Y (r x r), den = C + G with C = diag(+-1) (the first r_neg columns carry -1: leaf
-// vectors being removed), Gauss-Jordan with partial pivoting -> den^-1 and log|det den|; then
-// M = Y den^-1 (N x r).  With `y`: also v = Y'y and dquad = v' den^-1 v (the change of y'K^-1 y).
-// `logabsdet`, `M`, `y`/`dquad` may be null.
-__global__ __launch_bounds__(LR_THREADS) void small_kernel(const double *__restrict__ U, const double *__restrict__ Y,
-                                                           int N, int r, int r_neg, double *__restrict__ M,
+// One workgroup: G = the summed shares (r x r, then v: r entries) from reduce_shares_kernel, den = C + G with C = diag(+-1) (the first r_neg
+// columns carry -1: leaf vectors being removed), Gauss-Jordan with partial pivoting -> den^-1 (written to
+// `inv`, r x r) and log|det den|.  With `dquad`: v = sum of the v shares and dquad = v' den^-1 v (the change of
+// y'K^-1 y).  `logabsdet` / `dquad` may be null.
+__global__ __launch_bounds__(LR_THREADS) void small_kernel(const double *__restrict__ sums, int r, int r_neg,
+                                                           double *__restrict__ inv,
                                                            double *__restrict__ logabsdet, int *__restrict__ singular,
-                                                           const double *__restrict__ y, double *__restrict__ dquad) {
+                                                           double *__restrict__ dquad) {
     __shared__ double aug[LR_MAX][2 * LR_MAX + 1];  // [den | I]
+    __shared__ double vsh[LR_MAX];
     __shared__ int piv_row;
     const int tid = threadIdx.x;
-    // G[a][b] = sum_k U[k][a] Y[k][b]: one wave per (a,b) pair, lanes stride k, shuffle reduce
-    for (int e = tid >> 6; e < r * r; e += LR_THREADS / 64) {
-        const int a = e / r, bcol = e - a * r;
-        double g = 0.0;
-        for (int k = tid & 63; k < N; k += 64) g = fma(U[(size_t)k * r + a], Y[(size_t)k * r + bcol], g);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) g += __shfl_xor(g, off);
-        if ((tid & 63) == 0) {
+    for (int e = tid; e < r * r + r; e += LR_THREADS) {
+        const double g = sums[e];
+        if (e < r * r) {
+            const int a = e / r, bcol = e - a * r;
             aug[a][bcol] = g + (a == bcol ? (a < r_neg ? -1.0 : 1.0) : 0.0);
             aug[a][r + bcol] = (a == bcol) ? 1.0 : 0.0;
+        } else {
+            vsh[e - r * r] = g;
         }
     }
     __syncthreads();
@@ -116,30 +372,29 @@ __global__ __launch_bounds__(LR_THREADS) void small_kernel(const double *__restr
         __syncthreads();
     }
     if (tid == 0 && logabsdet) *logabsdet = logsum;
-    if (y && dquad) {  // v = Y'y (wave per column), dquad = v' den^-1 v
-        __shared__ double vsh[LR_MAX];
-        for (int a = tid >> 6; a < r; a += LR_THREADS / 64) {
-            double s = 0.0;
-            for (int k = tid & 63; k < N; k += 64) s = fma(Y[(size_t)k * r + a], y[k], s);
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-            if ((tid & 63) == 0) vsh[a] = s;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            double q = 0.0;
-            for (int a = 0; a < r; ++a)
-                for (int b2 = 0; b2 < r; ++b2) q = fma(vsh[a] * aug[a][r + b2], vsh[b2], q);
-            *dquad = q;
-        }
+    if (tid == 0 && dquad) {
+        double q = 0.0;
+        for (int a = 0; a < r; ++a)
+            for (int b2 = 0; b2 < r; ++b2) q = fma(vsh[a] * aug[a][r + b2], vsh[b2], q);
+        *dquad = q;
     }
-    if (M)
-        for (int e = tid; e < N * r; e += LR_THREADS) {
-            const int i = e / r, c = e - i * r;
-            double s = 0.0;
-            for (int a = 0; a < r; ++a) s = fma(Y[(size_t)i * r + a], aug[a][r + c], s);
-            M[e] = s;
-        }
+    if (inv)
+        for (int e = tid; e < r * r; e += LR_THREADS) inv[e] = aug[e / r][r + (e - (e / r) * r)];
+}
+
+// M = Y den^-1 (N x r): one thread per entry, den^-1 in LDS.
+__global__ __launch_bounds__(LR_THREADS) void left_factor_kernel(const double *__restrict__ Y,
+                                                                 const double *__restrict__ inv, int N, int r,
+                                                                 double *__restrict__ M) {
+    __shared__ double is[LR_MAX * LR_MAX];
+    for (int e = threadIdx.x; e < r * r; e += LR_THREADS) is[e] = inv[e];
+    __syncthreads();
+    const size_t e = (size_t)blockIdx.x * LR_THREADS + threadIdx.x;
+    if (e >= (size_t)N * r) return;
+    const int i = (int)(e / r), c = (int)(e - (size_t)i * r);
+    double s = 0.0;
+    for (int a = 0; a < r; ++a) s = fma(Y[(size_t)i * r + a], is[a * r + c], s);
+    M[e] = s;
 }
 
 // out[i][j] = K[i][j] - sum_a M[i][a] * R[j][a]     (R = Y for symmetric K_inv, else (U'K_inv)')
@@ -168,17 +423,117 @@ __global__ __launch_bounds__(LR_THREADS) void rank_update_kernel(const double *_
     }
 }
 
-template <int TRANS>
-void launch_skinny(dim3 grid, size_t lds, hipStream_t stream, const double *K, const double *U, int N, int r,
-                   double *out) {
+// U[i][c] = s if bit c of point i's one-hot leaf code is set else 0  (codes: [words][npad] planes)
+__global__ __launch_bounds__(LR_THREADS) void expand_onehot_kernel(const uint32_t *__restrict__ codes, int npad, int N,
+                                                                   int r, double s, double *__restrict__ U) {
+    const size_t e = (size_t)blockIdx.x * LR_THREADS + threadIdx.x;
+    if (e >= (size_t)N * r) return;
+    const int i = (int)(e / r), c = (int)(e - (size_t)i * r);
+    U[e] = ((codes[(size_t)(c >> 5) * npad + i] >> (c & 31)) & 1u) ? s : 0.0;
+}
+
+// rows per wave / chunk width per rank bound: enough workgroups and bytes in flight at small r, bounded
+// registers and LDS at large r
+template <int RT>
+struct SkinnyCfg {
+    static constexpr int RW = RT <= 16 ? SK_RW_SMALL : 2;
+    static constexpr int KL = RT <= 16 ? SK_KL_SMALL : 1;
+};
+
+template <int RT>
+int launch_skinny_rt(hipStream_t stream, const double *K, const double *U, int N, int r, double *out, const double *y,
+                     double *partial) {
+    constexpr int RW = SkinnyCfg<RT>::RW, KL = SkinnyCfg<RT>::KL, ROWS = 4 * RW;
+    const dim3 grid((unsigned)((N + ROWS - 1) / ROWS));
+    const size_t lds = (size_t)2 * (128 * KL + 2) * r * sizeof(double);  // 130 KiB at r = 64
+    if (N % 2 == 0) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)skinny_kernel<RT, true, RW, KL>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((skinny_kernel<RT, true, RW, KL>), grid, dim3(LR_THREADS), lds, stream, K, U, N, r, out, y,
+                           partial);
+    } else {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)skinny_kernel<RT, false, RW, KL>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((skinny_kernel<RT, false, RW, KL>), grid, dim3(LR_THREADS), lds, stream, K, U, N, r, out, y,
+                           partial);
+    }
+    return (int)grid.x;
+}
+
+// returns the number of workgroups (= shares written to `partial`)
+int launch_skinny(hipStream_t stream, const double *K, const double *U, int N, int r, double *out, const double *y,
+                  double *partial) {
+    if (r <= 8) return launch_skinny_rt<8>(stream, K, U, N, r, out, y, partial);
+    if (r <= 16) return launch_skinny_rt<16>(stream, K, U, N, r, out, y, partial);
+    if (r <= 32) return launch_skinny_rt<32>(stream, K, U, N, r, out, y, partial);
+    return launch_skinny_rt<64>(stream, K, U, N, r, out, y, partial);
+}
+
+// Column form K'U (== K U for symmetric K): usable when N is even and r <= 16.  `partial` may be null (no shares).
+bool colsum_usable(int64_t N, int64_t r) { return N % 2 == 0 && r <= 16; }
+
+int launch_colsum(hipStream_t stream, const double *K, const double *U, int N, int r, double *P, double *out,
+                  const double *y, double *partial) {
+    const int seg_rows = colsum_segment(N), segs = (N + seg_rows - 1) / seg_rows;
+    const dim3 grid((unsigned)((N + 127) / 128), (unsigned)segs);
+    const size_t lds = (size_t)4 * 128 * r * sizeof(double);  // 64 KiB at r = 16
     if (r <= 8)
-        hipLaunchKernelGGL((skinny_kernel<TRANS, 8>), grid, dim3(LR_THREADS), lds, stream, K, U, N, r, out);
-    else if (r <= 16)
-        hipLaunchKernelGGL((skinny_kernel<TRANS, 16>), grid, dim3(LR_THREADS), lds, stream, K, U, N, r, out);
-    else if (r <= 32)
-        hipLaunchKernelGGL((skinny_kernel<TRANS, 32>), grid, dim3(LR_THREADS), lds, stream, K, U, N, r, out);
+        hipLaunchKernelGGL((colsum_kernel<8>), grid, dim3(LR_THREADS), lds, stream, K, U, N, r, seg_rows, P);
     else
-        hipLaunchKernelGGL((skinny_kernel<TRANS, 64>), grid, dim3(LR_THREADS), lds, stream, K, U, N, r, out);
+        hipLaunchKernelGGL((colsum_kernel<16>), grid, dim3(LR_THREADS), lds, stream, K, U, N, r, seg_rows, P);
+    const int nblocks = (N + CS_FIN_ROWS - 1) / CS_FIN_ROWS;
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)nblocks), dim3(LR_THREADS),
+                       (size_t)(2 * CS_FIN_ROWS * r + CS_FIN_ROWS) * sizeof(double), stream, P, segs, U, N, r, out, y, partial);
+    return nblocks;
+}
+
+// shares -> sums -> den^-1, log|det|, dquad
+void launch_small(hipStream_t stream, const double *partial, int nblocks, int r, int r_neg, double *sums, double *inv,
+                  double *logabsdet, int *flag, double *dquad) {
+    const int per = r * r + r;
+    hipLaunchKernelGGL(reduce_shares_kernel, dim3((unsigned)((per + 3) / 4)), dim3(LR_THREADS), 0, stream, partial,
+                       nblocks, per, sums);
+    hipLaunchKernelGGL(small_kernel, dim3(1), dim3(LR_THREADS), 0, stream, sums, r, r_neg, inv, logabsdet, flag, dquad);
+}
+
+void launch_skinny_t(hipStream_t stream, const double *K, const double *U, int N, int r, double *out) {
+    const dim3 grid((unsigned)((N + LR_THREADS / 64 - 1) / (LR_THREADS / 64)));
+    const size_t lds = (size_t)64 * r * sizeof(double);
+    if (r <= 8)
+        hipLaunchKernelGGL((skinny_t_kernel<8>), grid, dim3(LR_THREADS), lds, stream, K, U, N, r, out);
+    else if (r <= 16)
+        hipLaunchKernelGGL((skinny_t_kernel<16>), grid, dim3(LR_THREADS), lds, stream, K, U, N, r, out);
+    else if (r <= 32)
+        hipLaunchKernelGGL((skinny_t_kernel<32>), grid, dim3(LR_THREADS), lds, stream, K, U, N, r, out);
+    else
+        hipLaunchKernelGGL((skinny_t_kernel<64>), grid, dim3(LR_THREADS), lds, stream, K, U, N, r, out);
+}
+
+// workspace: Y (N r) | R (N r) | M (N r) | den^-1 (r r) | sums (r r + r) | shares (<= N/4 blocks x (r r + r)) |
+//            P (segments x N r, column form only) | flag
+struct LowRankWs {
+    double *Y, *R, *M, *inv, *sums, *partial, *P;
+    int *flag;
+    size_t bytes;
+};
+
+LowRankWs lowrank_ws(void *base, int64_t N, int64_t r) {
+    LowRankWs w;
+    const int64_t max_blocks = (N + 3) / 4, per = r * r + r;
+    w.Y = static_cast<double *>(base);
+    w.R = w.Y + N * r;
+    w.M = w.R + N * r;
+    w.inv = w.M + N * r;
+    w.sums = w.inv + r * r;
+    w.partial = w.sums + per;
+    const int64_t seg_rows = colsum_segment(N);
+    const int64_t p_doubles = colsum_usable(N, r) ? (N + seg_rows - 1) / seg_rows * N * r : 0;
+    w.P = w.partial + (size_t)max_blocks * per;
+    w.flag = reinterpret_cast<int *>(w.P + p_doubles);
+    w.bytes = (size_t)(3 * N * r + r * r + per + max_blocks * per + p_doubles) * sizeof(double) + 64;
+    return w;
 }
 
 }  // namespace
@@ -190,7 +545,7 @@ extern "C" {
 
 size_t bark_lowrank_workspace_bytes(int64_t N, int64_t r) {
     if (N < 1 || r < 1 || r > LR_MAX) return 0;
-    return (size_t)(3 * N * r) * sizeof(double) + 64;  // Y, R, M + flag
+    return lowrank_ws(nullptr, N, r).bytes;
 }
 
 int bark_lowrank_update_hip(const double *K_inv, int64_t N, const double *U, int64_t r, int subtract, int symmetric,
@@ -204,30 +559,33 @@ int bark_lowrank_update_hip(const double *K_inv, int64_t N, const double *U, int
         return fail(BARK_ERR_WORKSPACE, "low-rank workspace too small");
     if (!K_out && !logabsdet_out) return fail(BARK_ERR_ARG, "nothing to compute");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    double *Y = static_cast<double *>(workspace);
-    double *R = Y + N * r;
-    double *M = R + N * r;
-    int *flag = reinterpret_cast<int *>(M + N * r);
+    const LowRankWs w = lowrank_ws(workspace, N, r);
     const int r_neg = subtract ? (int)r : 0;
-    const unsigned rows_per_block = LR_THREADS / 64;
-    const dim3 g1((unsigned)((N + rows_per_block - 1) / rows_per_block));
-    const size_t lds1 = (size_t)64 * r * sizeof(double);
-    launch_skinny<0>(g1, lds1, stream, K_inv, U, (int)N, (int)r, Y);
+    const bool colform = colsum_usable(N, r);
+    const int nblocks = (symmetric && colform)
+                            ? launch_colsum(stream, K_inv, U, (int)N, (int)r, w.P, w.Y, nullptr, w.partial)
+                            : launch_skinny(stream, K_inv, U, (int)N, (int)r, w.Y, nullptr, w.partial);
     BARK_LAUNCH_CHECK();
-    const double *Rp = Y;
+    const double *Rp = w.Y;
     if (K_out && !symmetric) {  // right factor U' K_inv as its own pass
-        launch_skinny<1>(g1, lds1, stream, K_inv, U, (int)N, (int)r, R);
+        if (colform)
+            launch_colsum(stream, K_inv, U, (int)N, (int)r, w.P, w.R, nullptr, nullptr);
+        else
+            launch_skinny_t(stream, K_inv, U, (int)N, (int)r, w.R);
         BARK_LAUNCH_CHECK();
-        Rp = R;
+        Rp = w.R;
     }
-    BARK_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), stream));
-    hipLaunchKernelGGL(small_kernel, dim3(1), dim3(LR_THREADS), 0, stream, U, Y, (int)N, (int)r, r_neg,
-                       K_out ? M : nullptr, logabsdet_out, flag, (const double *)nullptr, (double *)nullptr);
+    BARK_HIP_CHECK(hipMemsetAsync(w.flag, 0, sizeof(int), stream));
+    launch_small(stream, w.partial, nblocks, (int)r, r_neg, w.sums, K_out ? w.inv : nullptr, logabsdet_out, w.flag,
+                 nullptr);
     BARK_LAUNCH_CHECK();
     if (K_out) {
+        hipLaunchKernelGGL(left_factor_kernel, dim3((unsigned)((N * r + LR_THREADS - 1) / LR_THREADS)), dim3(LR_THREADS), 0,
+                           stream, w.Y, w.inv, (int)N, (int)r, w.M);
+        BARK_LAUNCH_CHECK();
         const dim3 g3((unsigned)((N + 63) / 64), (unsigned)((N + 63) / 64));
         hipLaunchKernelGGL(rank_update_kernel, g3, dim3(LR_THREADS), (size_t)2 * 64 * r * sizeof(double), stream, K_inv,
-                           M, Rp, (int)N, (int)r, K_out);
+                           w.M, Rp, (int)N, (int)r, K_out);
         BARK_LAUNCH_CHECK();
     }
     return BARK_OK;
@@ -252,33 +610,72 @@ int bark_lowrank_swap_eval_hip(const double *K_inv, int64_t N, const double *U, 
     if (r > LR_MAX) return fail(BARK_ERR_ARG, "tree swap supports r_old + r_new <= %d (got %lld)", LR_MAX, (long long)r);
     if (workspace_bytes < bark_lowrank_workspace_bytes(N, r)) return fail(BARK_ERR_WORKSPACE, "low-rank workspace too small");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    double *Y = static_cast<double *>(workspace);
-    double *M = Y + 2 * N * r;
-    int *flag = reinterpret_cast<int *>(M + N * r);
-    const unsigned rows_per_block = LR_THREADS / 64;
-    const dim3 g1((unsigned)((N + rows_per_block - 1) / rows_per_block));
-    launch_skinny<0>(g1, (size_t)64 * r * sizeof(double), stream, K_inv, U, (int)N, (int)r, Y);
+    const LowRankWs w = lowrank_ws(workspace, N, r);
+    const int nblocks = colsum_usable(N, r) ? launch_colsum(stream, K_inv, U, (int)N, (int)r, w.P, w.Y, y, w.partial)
+                                            : launch_skinny(stream, K_inv, U, (int)N, (int)r, w.Y, y, w.partial);
     BARK_LAUNCH_CHECK();
-    BARK_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), stream));
-    hipLaunchKernelGGL(small_kernel, dim3(1), dim3(LR_THREADS), 0, stream, U, Y, (int)N, (int)r, (int)r_old, M,
-                       scalars_out + 1, flag, y, scalars_out);
+    BARK_HIP_CHECK(hipMemsetAsync(w.flag, 0, sizeof(int), stream));
+    launch_small(stream, w.partial, nblocks, (int)r, (int)r_old, w.sums, w.inv, scalars_out + 1, w.flag, scalars_out);
     BARK_LAUNCH_CHECK();
     return BARK_OK;
 }
 
-int bark_lowrank_swap_apply_hip(const double *K_inv, int64_t N, int64_t r, const void *workspace, double *K_out,
+int bark_lowrank_swap_apply_hip(const double *K_inv, int64_t N, int64_t r, void *workspace, double *K_out,
                                 void *stream_) {
     error_buffer()[0] = 0;
     if (!K_inv || !K_out || !workspace || N < 1 || r < 1 || r > LR_MAX)
         return fail(BARK_ERR_ARG, "bark_lowrank_swap_apply_hip: bad argument");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const double *Y = static_cast<const double *>(workspace);
-    const double *M = Y + 2 * N * r;
+    const LowRankWs w = lowrank_ws(workspace, N, r);
+    hipLaunchKernelGGL(left_factor_kernel, dim3((unsigned)((N * r + LR_THREADS - 1) / LR_THREADS)), dim3(LR_THREADS), 0,
+                       stream, w.Y, w.inv, (int)N, (int)r, w.M);
+    BARK_LAUNCH_CHECK();
     const dim3 g3((unsigned)((N + 63) / 64), (unsigned)((N + 63) / 64));
-    hipLaunchKernelGGL(rank_update_kernel, g3, dim3(LR_THREADS), (size_t)2 * 64 * r * sizeof(double), stream, K_inv, M,
-                       Y, (int)N, (int)r, K_out);
+    hipLaunchKernelGGL(rank_update_kernel, g3, dim3(LR_THREADS), (size_t)2 * 64 * r * sizeof(double), stream, K_inv, w.M,
+                       w.Y, (int)N, (int)r, K_out);
     BARK_LAUNCH_CHECK();
     return BARK_OK;
+}
+
+// ---- the same proposal evaluated straight from the two trees ------------------------------------
+// `packed` is the device wire format of ONE forest of TWO trees [old tree, new tree] (bark_forest_pack with
+// B = 1, m = 2).  The one-hot leaf code of that pair IS the matrix [U_old U_new] / s of the reference's
+// get_leaf_vectors (forest.py:70-75) with one column per leaf of each tree: leaves no training point reaches
+// give zero columns, which leave log|det(C + G)| and v'(C + G)^-1 v unchanged.  r_old = leaves of the old tree
+// (bark_forest_pack_info of that tree alone: max_bits), s = sqrt(scale / m) (bark_sampler.py:233-236).
+// The workspace starts with the bark_lowrank_swap_eval_hip layout, so bark_lowrank_swap_apply_hip(K_inv, N,
+// info->max_bits, workspace, ...) commits an accepted proposal.
+size_t bark_tree_swap_workspace_bytes(int64_t N, int64_t r) {
+    if (N < 1 || r < 1 || r > LR_MAX) return 0;
+    const size_t base = round_up((int64_t)lowrank_ws(nullptr, N, r).bytes, 256);
+    const size_t codes = (size_t)((r + 31) / 32) * (size_t)bark_leaf_npad(N) * sizeof(uint32_t);
+    return base + round_up((int64_t)((size_t)N * r * sizeof(double)), 256) + codes;
+}
+
+int bark_tree_swap_eval_hip(const double *K_inv, int64_t N, const void *packed, const bark_pack_info *info,
+                            const double *X, int64_t d, int64_t r_old, double s, const double *y, double *scalars_out,
+                            void *workspace, size_t workspace_bytes, void *stream_) {
+    error_buffer()[0] = 0;
+    if (!K_inv || !packed || !info || !X || !y || !scalars_out || !workspace || N < 1 || d < 1 || N > (1 << 24))
+        return fail(BARK_ERR_ARG, "bark_tree_swap_eval_hip: bad argument");
+    if (info->B != 1 || info->m != 2)
+        return fail(BARK_ERR_ARG, "bark_tree_swap_eval_hip: pack the pair [old tree, new tree] as one forest (B = 1, m = 2)");
+    const int64_t r = info->max_bits;
+    if (r < 2 || r > LR_MAX) return fail(BARK_ERR_ARG, "tree swap supports 2..%d leaves in total (got %lld)", LR_MAX, (long long)r);
+    if (r_old < 1 || r_old >= r) return fail(BARK_ERR_ARG, "r_old = %lld is not inside (0, %lld)", (long long)r_old, (long long)r);
+    if (workspace_bytes < bark_tree_swap_workspace_bytes(N, r)) return fail(BARK_ERR_WORKSPACE, "tree-swap workspace too small");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    char *ws = static_cast<char *>(workspace);
+    const size_t base = round_up((int64_t)lowrank_ws(nullptr, N, r).bytes, 256);
+    double *U = reinterpret_cast<double *>(ws + base);
+    uint32_t *codes = reinterpret_cast<uint32_t *>(ws + base + round_up((int64_t)((size_t)N * r * sizeof(double)), 256));
+    const int words = (int)((r + 31) / 32);
+    int rc = walk_one_hot(packed, info, X, N, d, words, codes, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(expand_onehot_kernel, dim3((unsigned)((N * r + LR_THREADS - 1) / LR_THREADS)), dim3(LR_THREADS), 0,
+                       stream, codes, (int)bark_leaf_npad(N), (int)N, (int)r, s, U);
+    BARK_LAUNCH_CHECK();
+    return bark_lowrank_swap_eval_hip(K_inv, N, U, r_old, r - r_old, y, scalars_out, workspace, base, stream_);
 }
 
 }  // extern "C"

@@ -17,7 +17,9 @@ from __future__ import annotations
 import numpy as np
 
 from .. import _lib
-from ..forest import _is_torch, get_leaf_vectors
+import ctypes
+
+from ..forest import PackedForest, _as_nodes, _check_categorical, _feat_types, _is_torch, _points
 from .mll import batched_kernel_inverse
 
 
@@ -45,6 +47,18 @@ class ChainState:
                                                 _lib.stream_ptr()))
         self.quad = float(q.item())
         self._pending = None
+        self._ws = {}  # rank -> workspace tensor, reused across proposals
+        self._X_seen = None  # (caller's X object, validated device tensor) of the last propose_tree
+        self._scalars = torch.empty(2, dtype=torch.float64, device=self.K_inv.device)
+
+    def _workspace(self, r: int):
+        import torch
+
+        ws = self._ws.get(r)
+        if ws is None:
+            nbytes = int(_lib.lib().bark_tree_swap_workspace_bytes(self.N, r))  # >= the plain low-rank layout
+            ws = self._ws[r] = torch.empty(nbytes, dtype=torch.uint8, device=self.K_inv.device)
+        return ws
 
     @classmethod
     def from_forest(cls, forest, noise, scale, X, y, feat_types):
@@ -73,8 +87,7 @@ class ChainState:
             raise ValueError(f"tree swap supports at most 64 leaf vectors in total (got {r_old + r_new})")
         U = torch.cat([U_old, U_new], dim=1).contiguous()
         r = r_old + r_new
-        ws = torch.empty(int(lib.bark_lowrank_workspace_bytes(self.N, r)), dtype=torch.uint8, device=U.device)
-        scalars = torch.empty(2, dtype=torch.float64, device=U.device)
+        ws, scalars = self._workspace(r), self._scalars
         _lib.check(lib.bark_lowrank_swap_eval_hip(_lib.ptr(self.K_inv), self.N, _lib.ptr(U), r_old, r_new,
                                                   _lib.ptr(self.y), _lib.ptr(scalars), _lib.ptr(ws), ws.numel(),
                                                   _lib.stream_ptr()))
@@ -93,9 +106,32 @@ class ChainState:
         self._pending = None
 
     def propose_tree(self, old_nodes, new_nodes, X, feat_types, scale: float, m: int) -> float:
-        """Convenience for bark_sampler.py:233-256: leaf vectors of both trees (GPU walk), scaled by
-        s_sqrtm = sqrt(scale / m), then `propose`."""
-        s = float(np.sqrt(scale / m))
-        cur = get_leaf_vectors(old_nodes, X, feat_types)
-        new = get_leaf_vectors(new_nodes, X, feat_types)
-        return self.propose(cur * s, new * s)
+        """bark_sampler.py:233-256 from the two trees themselves: both are walked on the GPU and their one-hot
+        leaf code, scaled by s_sqrtm = sqrt(scale / m), is the [U_old U_new] of `propose` (one column per leaf;
+        leaves no point reaches give zero columns, which change nothing).  `accept()` commits as usual."""
+        lib = _lib.lib()
+        ft = _feat_types(feat_types)
+        if self._X_seen is None or self._X_seen[0] is not X:
+            Xd, _ = _points(X, ft.shape[0])
+            _check_categorical(Xd, ft)
+            self._X_seen = (X, Xd)
+        Xd = self._X_seen[1]
+        if Xd.shape[0] != self.N:
+            raise ValueError(f"X has {Xd.shape[0]} rows, the chain has {self.N} points")
+        old, new = _as_nodes(old_nodes, 1), _as_nodes(new_nodes, 1)
+        if old.ndim != 1 or new.ndim != 1 or old.shape != new.shape:
+            raise ValueError(f"trees must be (node_limit,) records of one container, got {old.shape} and {new.shape}")
+        info_old = _lib.PackInfo()
+        _lib.check(lib.bark_forest_pack_info(_lib.ptr(old), 1, 1, old.shape[0], _lib.ptr(ft), ft.shape[0],
+                                             ctypes.byref(info_old)))
+        pf = PackedForest(np.stack([old, new])[None], ft)
+        r, r_old = int(pf.info.max_bits), int(info_old.max_bits)
+        if r > 64:
+            raise ValueError(f"tree swap supports at most 64 leaves in total (got {r})")
+        ws, scalars = self._workspace(r), self._scalars
+        _lib.check(lib.bark_tree_swap_eval_hip(_lib.ptr(self.K_inv), self.N, _lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd),
+                                               Xd.shape[1], r_old, float(np.sqrt(scale / m)), _lib.ptr(self.y),
+                                               _lib.ptr(scalars), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+        dquad, dlogdet = (float(v) for v in scalars.cpu().numpy())
+        self._pending = (ws, r, self.quad - dquad, self.logdet + dlogdet)
+        return 0.5 * (-(self.quad - dquad) - (self.logdet + dlogdet))

@@ -124,8 +124,10 @@ class PackedForest:
         self.info = _lib.PackInfo()
         _lib.check(lib.bark_forest_pack_info(_lib.ptr(nodes3), B, m, L, _lib.ptr(ft), ft.shape[0],
                                              ctypes.byref(self.info)))
-        host = torch.empty(int(self.info.packed_bytes), dtype=torch.uint8).pin_memory() \
-            if torch.cuda.is_available() else torch.empty(int(self.info.packed_bytes), dtype=torch.uint8)
+        # pinned staging pays for sampler-sized outputs; pinning a few KiB (one tree pair) costs more than the copy
+        host = torch.empty(int(self.info.packed_bytes), dtype=torch.uint8)
+        if torch.cuda.is_available() and int(self.info.packed_bytes) >= (1 << 20):
+            host = host.pin_memory()
         _lib.check(lib.bark_forest_pack(_lib.ptr(nodes3), _lib.ptr(ft), ft.shape[0], ctypes.byref(self.info),
                                         ctypes.c_void_p(host.data_ptr())))
         self.packed = host.to(_lib.torch_device())

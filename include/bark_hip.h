@@ -209,8 +209,20 @@ int bark_lowrank_update_hip(const double *K_inv, int64_t N, const double *U, int
 int bark_lowrank_swap_eval_hip(const double *K_inv, int64_t N, const double *U, int64_t r_old, int64_t r_new,
                                const double *y, double *scalars_out, void *workspace, size_t workspace_bytes,
                                void *stream);
-int bark_lowrank_swap_apply_hip(const double *K_inv, int64_t N, int64_t r, const void *workspace, double *K_out,
+int bark_lowrank_swap_apply_hip(const double *K_inv, int64_t N, int64_t r, void *workspace, double *K_out,
                                 void *stream);
+
+/* The same proposal evaluated straight from the two trees (bark_sampler.py:233-257 incl. get_leaf_vectors,
+ * forest.py:70-75): `packed`/`info` = wire format of ONE forest made of the pair [old tree, new tree]
+ * (bark_forest_pack, B = 1, m = 2).  The pair's one-hot leaf code is [U_old U_new] / s with one column per leaf
+ * of each tree (unreached leaves give zero columns, which change neither scalar).  r_old = leaves of the old tree
+ * (max_bits of bark_forest_pack_info on that tree alone), s = sqrt(scale / m).  scalars_out as above.  The
+ * workspace (>= bark_tree_swap_workspace_bytes(N, info->max_bits)) begins with the swap_eval layout:
+ * bark_lowrank_swap_apply_hip(K_inv, N, info->max_bits, workspace, K_out, stream) commits the proposal. */
+size_t bark_tree_swap_workspace_bytes(int64_t N, int64_t r);
+int bark_tree_swap_eval_hip(const double *K_inv, int64_t N, const void *packed, const bark_pack_info *info,
+                            const double *X, int64_t d, int64_t r_old, double s, const double *y, double *scalars_out,
+                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* quick_inverse.py:37-38  mll(K_inv, K_logdet, y) = 0.5 * (-y' K_inv y - K_logdet), on device. */
 int bark_quadform_hip(const double *K_inv, const double *y, int64_t N, double *out, void *stream);

@@ -410,6 +410,20 @@ def test_woodbury_large_against_oracle(B):
                               B.orc.low_rank_det_update(K_inv, U, logdet, subtract=sub), rtol=1e-12)
     with pytest.raises(ValueError):
         qi.low_rank_inv_update(K_inv, rng.standard_normal((N, 65)))
+    # odd N (rows not 16-byte aligned -> scalar loads) that is not a multiple of the 8-row / 128-column tiling
+    N = 333
+    A = rng.standard_normal((N, N)) / np.sqrt(N)
+    K_inv = np.linalg.inv(A @ A.T + np.eye(N))
+    _, logdet = np.linalg.slogdet(A @ A.T + np.eye(N))
+    for r in (1, 5, 16):
+        U = rng.standard_normal((N, r)) * 0.05
+        for sub in (False, True):
+            want = B.orc.low_rank_inv_update(K_inv, U, subtract=sub)
+            assert np.allclose(qi.low_rank_inv_update(K_inv, U, subtract=sub), want, rtol=1e-9, atol=1e-11)
+            assert np.allclose(qi.low_rank_inv_update(K_inv, U, subtract=sub, assume_symmetric=True), want, rtol=1e-9,
+                               atol=1e-11)
+            assert np.isclose(qi.low_rank_det_update(K_inv, U, logdet, subtract=sub),
+                              B.orc.low_rank_det_update(K_inv, U, logdet, subtract=sub), rtol=1e-12)
 
 
 def test_single_large_matrix_split_k_path(B):
