@@ -58,6 +58,9 @@ SIGNATURES = {
     "bark_mll_leafspace_workspace_bytes": (ctypes.c_size_t, [i64, i64, i64, i64, i64]),
     "bark_mll_leafspace_hip": (ci, [vp, ctypes.POINTER(PackInfo), vp, i64, i64, vp, vp, vp, ci, vp, i64, vp, vp, vp, vp,
                                     vp, ctypes.c_size_t, i64, vp]),
+    "bark_kernel_inverse_leafspace_workspace_bytes": (ctypes.c_size_t, [i64, i64, i64, i64]),
+    "bark_kernel_inverse_leafspace_hip": (ci, [vp, ctypes.POINTER(PackInfo), vp, i64, i64, vp, vp, vp, ci, vp, vp, vp, vp,
+                                               vp, ctypes.c_size_t, i64, vp]),
     "bark_lowrank_workspace_bytes": (ctypes.c_size_t, [i64, i64]),
     "bark_lowrank_update_hip": (ci, [vp, i64, vp, i64, ci, ci, vp, vp, vp, ctypes.c_size_t, vp]),
     "bark_lowrank_swap_eval_hip": (ci, [vp, i64, vp, i64, i64, vp, vp, vp, ctypes.c_size_t, vp]),

@@ -50,6 +50,9 @@ int leafspace_prepare(const uint32_t *codes, int W, int npad, unsigned long long
 int leafspace_sumsq(const double *y, int N, double *out, hipStream_t s);
 int leafspace_predict(const uint32_t *ccodes, int W, int cpad, int C, const double *w, const double *Minv, int R,
                       const double *noise, const double *scale, int m, int bc, double *mu, double *var, hipStream_t s);
+int leafspace_inverse(const uint32_t *codes, int W, int npad, int N, const double *Minv, const double *w, int R,
+                      const double *y, const double *noise, const double *scale, int m, int bc, double *Wm, double *kinv,
+                      double *kinv_y, hipStream_t s);
 int leafspace_finish(const double *accum, const double *yy, const double *noise, const double *scale, int m, int bc, int N,
                      int include_2pi, double *mll, hipStream_t s);
 
@@ -1210,17 +1213,20 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
 struct LeafLayout {
     Layout L;         // the R x R sweep workspace (N := R; candidates := R identity columns for the posterior)
     int64_t R, Rpad, W, npad, Q, cpad;
-    size_t off_codes, off_planes, off_yy, off_ccodes, off_minv, off_w, total;
+    size_t off_codes, off_planes, off_yy, off_ccodes, off_minv, off_w, off_wm, total;
 };
 
-static LeafLayout make_leaf_layout(int64_t N, int64_t max_bits, int64_t m, int64_t Bc, int64_t C = 0) {
+// C > 0: posterior at C candidates; want_inverse: explicit K_s^-1.  Either needs M^-1 (identity columns in the sweep).
+static LeafLayout make_leaf_layout(int64_t N, int64_t max_bits, int64_t m, int64_t Bc, int64_t C = 0,
+                                   bool want_inverse = false) {
     LeafLayout g;
+    const bool want_minv = C > 0 || want_inverse;
     g.R = max_bits;
     g.Rpad = round_up(max_bits, NB);
     g.W = (max_bits + 31) / 32;
     g.npad = round_up(N, NB);
     g.Q = g.npad / 64;
-    g.L = make_layout(max_bits, C > 0 ? max_bits : 0, m, Bc);
+    g.L = make_layout(max_bits, want_minv ? max_bits : 0, m, Bc);
     g.cpad = C > 0 ? round_up(C, NB) : 0;
     size_t o = g.L.total;
     g.off_codes = o;
@@ -1232,11 +1238,18 @@ static LeafLayout make_leaf_layout(int64_t N, int64_t max_bits, int64_t m, int64
     g.off_ccodes = o;
     o = align256(o + (size_t)Bc * g.W * g.cpad * sizeof(uint32_t));
     g.off_minv = o;
-    if (C > 0) o = align256(o + (size_t)Bc * max_bits * max_bits * sizeof(double));
+    if (want_minv) o = align256(o + (size_t)Bc * max_bits * max_bits * sizeof(double));
     g.off_w = o;
-    if (C > 0) o = align256(o + (size_t)Bc * max_bits * sizeof(double));
+    if (want_minv) o = align256(o + (size_t)Bc * max_bits * sizeof(double));
+    g.off_wm = o;
+    if (want_inverse) o = align256(o + (size_t)Bc * N * max_bits * sizeof(double));
     g.total = o;
     return g;
+}
+
+size_t bark_kernel_inverse_leafspace_workspace_bytes(int64_t N, int64_t max_bits, int64_t m, int64_t Bc) {
+    if (N < 1 || max_bits < 1 || m < 1 || Bc < 1) return 0;
+    return make_leaf_layout(N, max_bits, m, Bc, 0, true).total;
 }
 
 size_t bark_mll_leafspace_workspace_bytes(int64_t N, int64_t max_bits, int64_t m, int64_t Bc, int64_t C) {
@@ -1244,13 +1257,17 @@ size_t bark_mll_leafspace_workspace_bytes(int64_t N, int64_t max_bits, int64_t m
     return make_leaf_layout(N, max_bits, m, Bc, C).total;
 }
 
-int bark_mll_leafspace_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
-                           const double *y, const double *noise, const double *scale, int flags, const double *cand,
-                           int64_t C, double *mll_out, double *mu_out, double *var_out, int32_t *info_out,
-                           void *workspace, size_t workspace_bytes, int64_t Bc, void *stream_) {
+}  // extern "C"
+
+// shared driver of the leaf-space entry points: MLL always; posterior when C > 0; explicit inverse when kinv_out
+static int leafspace_run(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
+                         const double *y, const double *noise, const double *scale, int flags, const double *cand,
+                         int64_t C, double *mll_out, double *mu_out, double *var_out, double *kinv_out,
+                         double *kinv_y_out, int32_t *info_out, void *workspace, size_t workspace_bytes, int64_t Bc,
+                         void *stream_) {
     error_buffer()[0] = 0;
     if (!packed || !info || !X || !y || !noise || !mll_out || !info_out || !workspace)
-        return fail(BARK_ERR_ARG, "bark_mll_leafspace_hip: null argument");
+        return fail(BARK_ERR_ARG, "leaf-space entry: null argument");
     const int64_t B = info->B, m = info->m;
     if (N < 1 || d < 1 || B < 1 || Bc < 1 || C < 0 || N > (1 << 24) || C > (1 << 24))
         return fail(BARK_ERR_ARG, "bark_mll_leafspace_hip: bad shape N=%lld d=%lld B=%lld Bc=%lld C=%lld", (long long)N,
@@ -1262,7 +1279,9 @@ int bark_mll_leafspace_hip(const void *packed, const bark_pack_info *info, const
     if (info->max_bits > 8192) return fail(BARK_ERR_ARG, "leaf-space path supports at most 8192 leaves per forest");
     if (Bc > B) Bc = B;
     if (Bc > 65535) Bc = 65535;
-    const LeafLayout g = make_leaf_layout(N, info->max_bits, m, Bc, C);
+    const bool want_minv = C > 0 || kinv_out != nullptr;
+    if (kinv_out && info->max_bits > 65535) return fail(BARK_ERR_ARG, "leaf-space inverse: too many leaves");
+    const LeafLayout g = make_leaf_layout(N, info->max_bits, m, Bc, C, kinv_out != nullptr);
     if (workspace_bytes < g.total) return fail(BARK_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", workspace_bytes, g.total);
     if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(BARK_ERR_ARG, "workspace must be 256-byte aligned");
     int rc = set_lds_limits();
@@ -1319,7 +1338,7 @@ int bark_mll_leafspace_hip(const void *packed, const bark_pack_info *info, const
                                use_scale ? scale + c0 : nullptr, (int)m, (int)bc, p.A, p.ld, p.bstride, y, (int)N, p.yz,
                                p.accum, p.info, caller);
         if (rc) return rc;
-        if (C > 0) {  // right-hand side block := I_R, so the sweep also yields V = U^-T
+        if (want_minv) {  // right-hand side block := I_R, so the sweep also yields V = U^-T
             dim3 gi((unsigned)((g.L.cpad + 255) / 256), (unsigned)g.L.npad, (unsigned)bc);
             hipLaunchKernelGGL(identity_rhs_kernel, gi, dim3(256), 0, caller, p, (int)g.R, (int)g.L.cpad);
             BARK_LAUNCH_CHECK();
@@ -1329,7 +1348,7 @@ int bark_mll_leafspace_hip(const void *packed, const bark_pack_info *info, const
         rc = leafspace_finish(p.accum, yy, noise + c0, use_scale ? scale + c0 : nullptr, (int)m, (int)bc, (int)N,
                               (flags & BARK_MLL_INCLUDE_2PI) ? 1 : 0, mll_out + c0, caller);
         if (rc) return rc;
-        if (C > 0) {
+        if (want_minv) {
             // w = M^-1 v = V'z and M^-1 = V'V (the same kernels the dense posterior / inverse export use)
             const int R = (int)g.R;
             hipLaunchKernelGGL(predict_reduce_kernel, dim3((unsigned)((R + 255) / 256), (unsigned)bc), dim3(256), 0, caller, p, R,
@@ -1339,13 +1358,44 @@ int bark_mll_leafspace_hip(const void *packed, const bark_pack_info *info, const
             hipLaunchKernelGGL(vtv_kernel, dim3(xcd_grid(nct * nct, (int)bc)), dim3(THREADS), GEMM_LDS, caller, p, nct, R,
                                (const double *)nullptr, 1.0, 1, Minv);
             BARK_LAUNCH_CHECK();
-            if ((rc = walk_one_hot(packed_c, &sub, cand, C, d, (int)g.W, ccodes, caller))) return rc;
-            rc = leafspace_predict(ccodes, (int)g.W, (int)g.cpad, (int)C, wvec, Minv, R, noise + c0, scale + c0, (int)m,
-                                   (int)bc, mu_out + (size_t)c0 * C, var_out + (size_t)c0 * C, caller);
-            if (rc) return rc;
+            if (C > 0) {
+                if ((rc = walk_one_hot(packed_c, &sub, cand, C, d, (int)g.W, ccodes, caller))) return rc;
+                rc = leafspace_predict(ccodes, (int)g.W, (int)g.cpad, (int)C, wvec, Minv, R, noise + c0, scale + c0, (int)m,
+                                       (int)bc, mu_out + (size_t)c0 * C, var_out + (size_t)c0 * C, caller);
+                if (rc) return rc;
+            }
+            if (kinv_out) {
+                rc = leafspace_inverse(codes, (int)g.W, (int)g.npad, (int)N, Minv, wvec, R, y, noise + c0,
+                                       use_scale ? scale + c0 : nullptr, (int)m, (int)bc,
+                                       reinterpret_cast<double *>(ws + g.off_wm), kinv_out + (size_t)c0 * N * N,
+                                       kinv_y_out ? kinv_y_out + (size_t)c0 * N : nullptr, caller);
+                if (rc) return rc;
+            }
         }
     }
     return BARK_OK;
+}
+
+extern "C" {
+
+int bark_mll_leafspace_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
+                           const double *y, const double *noise, const double *scale, int flags, const double *cand,
+                           int64_t C, double *mll_out, double *mu_out, double *var_out, int32_t *info_out,
+                           void *workspace, size_t workspace_bytes, int64_t Bc, void *stream_) {
+    return leafspace_run(packed, info, X, N, d, y, noise, scale, flags, cand, C, mll_out, mu_out, var_out, nullptr, nullptr,
+                         info_out, workspace, workspace_bytes, Bc, stream_);
+}
+
+int bark_kernel_inverse_leafspace_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
+                                      const double *y, const double *noise, const double *scale, int flags,
+                                      double *mll_out, double *kinv_out, double *kinv_y_out, int32_t *info_out,
+                                      void *workspace, size_t workspace_bytes, int64_t Bc, void *stream_) {
+    if (!kinv_out) {
+        error_buffer()[0] = 0;
+        return fail(BARK_ERR_ARG, "bark_kernel_inverse_leafspace_hip: kinv_out is null");
+    }
+    return leafspace_run(packed, info, X, N, d, y, noise, scale, flags, nullptr, 0, mll_out, nullptr, nullptr, kinv_out,
+                         kinv_y_out, info_out, workspace, workspace_bytes, Bc, stream_);
 }
 
 int bark_quadform_hip(const double *K_inv, const double *y, int64_t N, double *out, void *stream_) {

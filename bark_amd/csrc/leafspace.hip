@@ -171,6 +171,86 @@ __global__ __launch_bounds__(128) void leaf_predict_kernel(const uint32_t *__res
     var[(size_t)b * C + c] = sc / (double)m * s2;
 }
 
+
+// Explicit inverse in leaf space:  K_s^-1 = (I - c Z M^-1 Z') / sigma2,   K_s^-1 y = (y - c Z w) / sigma2.
+// Step 1 (one wave per point i):  Wm[i][q] = sum_{a in L(i)} Minv[a][q]  (row i of Z M^-1) and zy_i = sum w_a.
+// The leaf list is decoded from the one-hot code with wave-uniform control flow (no per-lane list).
+__global__ __launch_bounds__(256) void leaf_rowsum_kernel(const uint32_t *__restrict__ codes, int W, int npad, int N,
+                                                          const double *__restrict__ Minv, const double *__restrict__ w,
+                                                          int R, const double *__restrict__ y,
+                                                          const double *__restrict__ noise, const double *__restrict__ scale,
+                                                          int m, double *__restrict__ Wm, double *__restrict__ kinv_y) {
+    const int lane = threadIdx.x & 63, b = blockIdx.y;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= N) return;  // no barriers below
+    const double *Mb = Minv + (size_t)b * R * R;
+    const double *wb = w + (size_t)b * R;
+    double *dst = Wm + ((size_t)b * N + i) * R;
+    for (int qb = 0; qb < R; qb += 256) {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        double sw = 0.0;
+        for (int wd = 0; wd < W; ++wd) {
+            uint32_t bits = __builtin_amdgcn_readfirstlane(codes[((size_t)b * W + wd) * npad + i]);
+            while (bits) {
+                const int a = 32 * wd + __builtin_ctz(bits);
+                bits &= bits - 1;
+                const double *row = Mb + (size_t)a * R + qb + lane;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (qb + 64 * u + lane < R) acc[u] += row[64 * u];
+                sw += wb[a];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (qb + 64 * u + lane < R) dst[qb + 64 * u + lane] = acc[u];
+        if (qb == 0 && lane == 0 && kinv_y) {
+            const double sigma2 = 1e-6 + noise[b];
+            const double coef = (scale ? scale[b] : 1.0) / ((double)m * sigma2);
+            kinv_y[(size_t)b * N + i] = (y[i] - coef * sw) / sigma2;
+        }
+    }
+}
+
+// Step 2 (64 x 64 tile of the output):  out[i][j] = ([i == j] - c sum_{q in L(j)} Wm[i][q]) / sigma2.
+// The leaf lists of the tile's 64 columns sit in LDS ([tree][column], conflict-free); a wave owns a row at a time,
+// so its gathers stay inside one row of Wm (R doubles, L1-resident) and the store is one 512-byte segment.
+__global__ __launch_bounds__(256) void leaf_inverse_kernel(const uint32_t *__restrict__ codes, int W, int npad, int N,
+                                                           const double *__restrict__ Wm, int R,
+                                                           const double *__restrict__ noise, const double *__restrict__ scale,
+                                                           int m, double *__restrict__ out) {
+    extern __shared__ unsigned short idx[];  // [m][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.z;
+    const int col0 = blockIdx.x * 64, row0 = blockIdx.y * 64;
+    const int j = col0 + lane;
+    if (threadIdx.x < 64) {
+        int n = 0;
+        if (j < N)
+            for (int wd = 0; wd < W && n < m; ++wd) {
+                uint32_t bits = codes[((size_t)b * W + wd) * npad + j];
+                while (bits && n < m) {
+                    idx[n * 64 + lane] = (unsigned short)(32 * wd + __builtin_ctz(bits));
+                    bits &= bits - 1;
+                    ++n;
+                }
+            }
+        for (; n < m; ++n) idx[n * 64 + lane] = 0;
+    }
+    __syncthreads();
+    const double sigma2 = 1e-6 + noise[b];
+    const double coef = (scale ? scale[b] : 1.0) / ((double)m * sigma2);
+    const double inv_s2 = 1.0 / sigma2;
+    for (int q = wave; q < 64; q += 4) {
+        const int i = row0 + q;
+        if (i >= N || j >= N) continue;
+        const double *wrow = Wm + ((size_t)b * N + i) * R;
+        double acc = 0.0;
+#pragma unroll 4
+        for (int t = 0; t < m; ++t) acc += wrow[idx[t * 64 + lane]];
+        out[((size_t)b * N + i) * N + j] = ((i == j ? 1.0 : 0.0) - coef * acc) * inv_s2;
+    }
+}
+
 }  // namespace
 
 int leafspace_predict(const uint32_t *ccodes, int W, int cpad, int C, const double *w, const double *Minv, int R,
@@ -182,8 +262,19 @@ int leafspace_predict(const uint32_t *ccodes, int W, int cpad, int C, const doub
     return BARK_OK;
 }
 
-namespace {
-}  // namespace
+int leafspace_inverse(const uint32_t *codes, int W, int npad, int N, const double *Minv, const double *w, int R,
+                      const double *y, const double *noise, const double *scale, int m, int bc, double *Wm, double *kinv,
+                      double *kinv_y, hipStream_t s) {
+    if (R > 65535 || m > 16384) return fail(BARK_ERR_ARG, "leaf-space inverse: forest too large (R = %d, m = %d)", R, m);
+    hipLaunchKernelGGL(leaf_rowsum_kernel, dim3((unsigned)((N + 3) / 4), (unsigned)bc), dim3(256), 0, s, codes, W, npad, N, Minv,
+                       w, R, y, noise, scale, m, Wm, kinv_y);
+    BARK_LAUNCH_CHECK();
+    const unsigned tiles = (unsigned)((N + 63) / 64);
+    hipLaunchKernelGGL(leaf_inverse_kernel, dim3(tiles, tiles, (unsigned)bc), dim3(256), (size_t)m * 64 * sizeof(unsigned short),
+                       s, codes, W, npad, N, Wm, R, noise, scale, m, kinv);
+    BARK_LAUNCH_CHECK();
+    return BARK_OK;
+}
 
 // launchers used by the entry point in chol.hip -----------------------------------------------------------
 int leafspace_prepare(const uint32_t *codes, int W, int npad, unsigned long long *planes, int R, int Rpad,

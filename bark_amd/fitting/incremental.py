@@ -20,7 +20,7 @@ from .. import _lib
 import ctypes
 
 from ..forest import PackedForest, _as_nodes, _check_categorical, _feat_types, _is_torch, _points
-from .mll import batched_kernel_inverse
+from .mll import _run_leafspace, batched_kernel_inverse
 
 
 def _dev64(a):
@@ -68,6 +68,16 @@ class ChainState:
                                                   return_device=True)
         return cls(K_inv[0], float(logdet[0].item()), y)
 
+    def propose_noise_scale(self, forest, new_noise: float, new_scale: float, X, feat_types) -> float:
+        """MLL the chain would have with the proposed (noise, scale) — the second half of `_step_bark_sampler`
+        (bark_sampler.py:266-272), where the reference rebuilds inv + slogdet of the N x N matrix.  Evaluated in
+        leaf space (R x R system, include/bark_hip.h) without touching K_inv; `accept()` rebuilds the resident
+        inverse, also in leaf space.  `forest` is the chain's current (m, node_limit) forest."""
+        nodes = np.asarray(forest)
+        val = _run_leafspace(nodes[None], [new_noise], [new_scale], X, self.y, feat_types, _lib.MLL_INCLUDE_SCALE)
+        self._pending = ("noise_scale", nodes, float(new_noise), float(new_scale), X, feat_types)
+        return float(val[0].item())
+
     @property
     def mll(self) -> float:
         """quick_inverse.py:37-38."""
@@ -99,6 +109,15 @@ class ChainState:
         """Commit the last proposal: K_inv <- K_inv - Y (C+G)^-1 Y' (bark_sampler.py:259-264)."""
         if self._pending is None:
             raise RuntimeError("accept() without a pending propose()")
+        if self._pending[0] == "noise_scale":
+            _, nodes, noise, scale, X, feat_types = self._pending
+            K_inv, K_inv_y, logdet = batched_kernel_inverse(nodes[None], [noise], [scale], X, self.y, feat_types,
+                                                            no_null=False, return_device=True, method="leafspace")
+            self.K_inv = K_inv[0]
+            self.quad = float((K_inv_y[0] @ self.y).item())
+            self.logdet = float(logdet[0].item())
+            self._pending = None
+            return
         ws, r, quad, logdet = self._pending
         _lib.check(_lib.lib().bark_lowrank_swap_apply_hip(_lib.ptr(self.K_inv), self.N, r, _lib.ptr(ws),
                                                           _lib.ptr(self.K_inv), _lib.stream_ptr()))

@@ -107,9 +107,7 @@ def _run(forest, noise, scale, X, y, feat_types, flags, cand=None, timing=None, 
         if want_cov:
             cov = torch.empty((B, C, C), dtype=torch.float64, device=Xd.device)
     pf = PackedForest(nodes3, ft)
-    held = 0 if cov is None else cov.numel() * 8
     Bc = chunk or choose_chunk(B, N, C, pf.m)
-    del held
     nbytes = int(lib.bark_mll_workspace_bytes(N, C, pf.m, Bc))
     ws = _lib.workspace(nbytes)
     out = torch.empty(B, dtype=torch.float64, device=Xd.device)
@@ -129,7 +127,7 @@ def _run(forest, noise, scale, X, y, feat_types, flags, cand=None, timing=None, 
 
 
 def batched_kernel_inverse(forest, noise, scale, X, y, feat_types, *, no_null: bool = True, return_device=False,
-                           chunk: int | None = None):
+                           chunk: int | None = None, method: str = "dense"):
     """Explicit inverse of the GP kernel matrix of each forest sample, as the acquisition builder needs it
     (src/bark/optimizer/opt_model.py:54-59,101):
 
@@ -139,10 +137,22 @@ def batched_kernel_inverse(forest, noise, scale, X, y, feat_types, *, no_null: b
         logdet  = log|K_s|          (B,)
 
     Computed from the Cholesky factor (K_inv = U^-1 U^-T: the same sweep with an identity right-hand
-    side, then one MFMA V'V product) instead of the reference's LU `np.linalg.inv`."""
+    side, then one MFMA V'V product) instead of the reference's LU `np.linalg.inv`.
+
+    method="leafspace" (no_null=False only) builds the same three results from the R x R leaf-space system,
+    K_inv = (I - c Z M^-1 Z') / sigma2 (include/bark_hip.h) — what a single chain's noise/scale step wants,
+    where one N x N factorisation cannot fill the GPU."""
     nodes = _as_nodes(forest, 2)
     nodes3 = nodes.reshape(-1, *nodes.shape[-2:])
     scale = np.asarray(scale, dtype=np.float64).reshape(-1)
+    if method == "leafspace":
+        if no_null:
+            raise ValueError("method='leafspace' supports no_null=False only")
+        mll_noconst, K_inv_y, K_inv = _run_leafspace(nodes3, noise, scale, X, y, feat_types, _lib.MLL_INCLUDE_SCALE,
+                                                     chunk=chunk, want_inverse=True)
+        return _inverse_results(mll_noconst, K_inv_y, K_inv, X, y, return_device)
+    if method != "dense":
+        raise ValueError(f"unknown method {method!r} (use 'dense' or 'leafspace')")
     shift = None
     if no_null:  # forest.py:102-111 folded into (shift, scale)
         num_trees = nodes3.shape[-2]
@@ -152,7 +162,11 @@ def batched_kernel_inverse(forest, noise, scale, X, y, feat_types, *, no_null: b
     flags = _lib.MLL_INCLUDE_SCALE | _lib.MLL_RHS_IDENTITY
     mll_noconst, K_inv_y, _, K_inv = _run(nodes3, noise, scale, X, y, feat_types, flags, chunk=chunk, shift=shift,
                                           want_cov=True)
-    # mll = 0.5(-y'K^-1 y - logdet)  =>  logdet = -2 mll - y'K^-1 y
+    return _inverse_results(mll_noconst, K_inv_y, K_inv, X, y, return_device)
+
+
+def _inverse_results(mll_noconst, K_inv_y, K_inv, X, y, return_device):
+    """mll = 0.5(-y'K^-1 y - logdet)  =>  logdet = -2 mll - y'K^-1 y."""
     import torch
 
     yd = _lib.to_device(y.detach() if _is_torch(y) else np.asarray(y, dtype=np.float64)).to(torch.float64).reshape(-1)
@@ -162,9 +176,10 @@ def batched_kernel_inverse(forest, noise, scale, X, y, feat_types, *, no_null: b
     return K_inv.cpu().numpy(), K_inv_y.cpu().numpy(), logdet.cpu().numpy()
 
 
-def _run_leafspace(forest, noise, scale, X, y, feat_types, flags, chunk=None, cand=None):
+def _run_leafspace(forest, noise, scale, X, y, feat_types, flags, chunk=None, cand=None, want_inverse=False):
     """Leaf-space evaluation (bark_mll_leafspace_hip): R x R system instead of N x N.
-    Returns the (B,) MLL tensor, or (mll, mu, var) when candidates are given."""
+    Returns the (B,) MLL tensor, (mll, mu, var) when candidates are given, or (mll, K_inv_y, K_inv) with
+    `want_inverse` (bark_kernel_inverse_leafspace_hip)."""
     import torch
 
     lib = _lib.lib()
@@ -193,17 +208,33 @@ def _run_leafspace(forest, noise, scale, X, y, feat_types, flags, chunk=None, ca
         var = torch.empty((B, C), dtype=torch.float64, device=Xd.device)
     pf = PackedForest(nodes3, ft)
     Bc = int(chunk or B)
-    ws = _lib.workspace(int(lib.bark_mll_leafspace_workspace_bytes(N, int(pf.info.max_bits), pf.m, Bc, C)))
     out = torch.empty(B, dtype=torch.float64, device=Xd.device)
     info = torch.empty(B, dtype=torch.int32, device=Xd.device)
-    _lib.check(lib.bark_mll_leafspace_hip(_lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(yd),
-                                          _lib.ptr(noise_d), _lib.ptr(scale_d), flags, _lib.ptr(cand_d), C,
-                                          _lib.ptr(out), _lib.ptr(mu), _lib.ptr(var), _lib.ptr(info),
-                                          _lib.ptr(ws), ws.numel(), Bc, _lib.stream_ptr()))
+    K_inv = K_inv_y = None
+    if want_inverse:
+        if cand is not None:
+            raise ValueError("candidates and want_inverse are separate calls")
+        if chunk is None:  # keep the (Bc, N, R) row-sum scratch modest next to the (B, N, N) result
+            Bc = max(1, min(B, (1 << 30) // max(1, 8 * N * int(pf.info.max_bits))))
+        ws = _lib.workspace(int(lib.bark_kernel_inverse_leafspace_workspace_bytes(N, int(pf.info.max_bits), pf.m, Bc)))
+        K_inv = torch.empty((B, N, N), dtype=torch.float64, device=Xd.device)
+        K_inv_y = torch.empty((B, N), dtype=torch.float64, device=Xd.device)
+        _lib.check(lib.bark_kernel_inverse_leafspace_hip(_lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(yd),
+                                                         _lib.ptr(noise_d), _lib.ptr(scale_d), flags, _lib.ptr(out),
+                                                         _lib.ptr(K_inv), _lib.ptr(K_inv_y), _lib.ptr(info), _lib.ptr(ws),
+                                                         ws.numel(), Bc, _lib.stream_ptr()))
+    else:
+        ws = _lib.workspace(int(lib.bark_mll_leafspace_workspace_bytes(N, int(pf.info.max_bits), pf.m, Bc, C)))
+        _lib.check(lib.bark_mll_leafspace_hip(_lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(yd),
+                                              _lib.ptr(noise_d), _lib.ptr(scale_d), flags, _lib.ptr(cand_d), C,
+                                              _lib.ptr(out), _lib.ptr(mu), _lib.ptr(var), _lib.ptr(info),
+                                              _lib.ptr(ws), ws.numel(), Bc, _lib.stream_ptr()))
     bad = info.cpu().numpy()
     if bad.any():
         b = int(np.flatnonzero(bad)[0])
         raise np.linalg.LinAlgError(f"leaf-space system of forest sample {b} is not positive definite")
+    if want_inverse:
+        return out, K_inv_y, K_inv
     return out if cand is None else (out, mu, var)
 
 

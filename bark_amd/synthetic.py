@@ -153,7 +153,8 @@ def mixed_problem(N, seed, d_cont=8, n_int=2, n_cat=2, cats=5):
         bounds.append((0.0, float((1 << cats) - 1))); ft.append(CAT)
     X = np.stack(cols, axis=1)
     y = rng.standard_normal((N, 1))
-    y = (y - y.mean()) / y.std()
+    spread = y.std()
+    y = (y - y.mean()) / (spread if spread > 0 else 1.0)  # N = 1: a single centred target
     return X, y, np.array(bounds), np.array(ft, dtype=np.int64)
 
 

@@ -186,6 +186,18 @@ int bark_mll_leafspace_hip(const void *packed, const bark_pack_info *info, const
                            int64_t C, double *mll_out, double *mu_out, double *var_out, int32_t *info_out,
                            void *workspace, size_t workspace_bytes, int64_t Bc, void *stream);
 
+/* Explicit inverse in the same leaf space — what the sampler rebuilds after every noise/scale proposal
+ * (bark_sampler.py:267-272: inv + slogdet of scale K + (1e-6 + noise) I) and the acquisition builder reads
+ * (opt_model.py:54-59) — without factorising the N x N matrix:
+ *   K_s^-1 = (I - c Z M^-1 Z') / s2 ,   K_s^-1 y = (y - c Z w) / s2 ,   log|K_s| = -2 mll - y'K_s^-1 y
+ * (mll in the convention selected by `flags`, as above).  kinv_out: (B, N, N); kinv_y_out: (B, N) or NULL.
+ * Cost: the R x R sweep with an identity right-hand side + N R m + N^2 m gathered adds. */
+size_t bark_kernel_inverse_leafspace_workspace_bytes(int64_t N, int64_t max_bits, int64_t m, int64_t Bc);
+int bark_kernel_inverse_leafspace_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N,
+                                      int64_t d, const double *y, const double *noise, const double *scale, int flags,
+                                      double *mll_out, double *kinv_out, double *kinv_y_out, int32_t *info_out,
+                                      void *workspace, size_t workspace_bytes, int64_t Bc, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Woodbury / determinant-lemma updates — quick_inverse.py:13-33 (the per-tree step of the sampler,
  * bark_sampler.py:233-257).  With mul = -1 if `subtract` else +1:

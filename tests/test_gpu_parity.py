@@ -308,6 +308,16 @@ def test_kernel_inverse_for_acquisition_builder(B):
         assert np.allclose(K_inv_y, (want @ y)[..., 0], rtol=1e-8, atol=1e-9)
         assert np.allclose(logdet, np.linalg.slogdet(K_s)[1], rtol=1e-10)
         assert np.allclose(K_inv @ K_s, np.eye(257)[None], atol=1e-8)
+        if not no_null:  # the same three results from the R x R leaf-space system
+            L_inv, L_inv_y, L_logdet = B.fit.batched_kernel_inverse(forest, noise, scale, X, y, ft, no_null=False,
+                                                                    method="leafspace")
+            assert np.allclose(L_inv, want, rtol=1e-8, atol=1e-9)
+            assert np.allclose(L_inv_y, (want @ y)[..., 0], rtol=1e-8, atol=1e-9)
+            assert np.allclose(L_logdet, np.linalg.slogdet(K_s)[1], rtol=1e-10)
+            one = B.fit.batched_kernel_inverse(forest, noise, scale, X, y, ft, no_null=False, method="leafspace", chunk=1)
+            assert np.array_equal(one[0], L_inv)  # chunking does not change the arithmetic
+    with pytest.raises(ValueError):
+        B.fit.batched_kernel_inverse(forest, noise, scale, X, y, ft, no_null=True, method="leafspace")
 
 
 def test_g9_woodbury_updates(B):
@@ -388,6 +398,24 @@ def test_fused_tree_swap_matches_reference_chain(B):
     assert np.isclose(state.logdet, np.linalg.slogdet(K)[1], rtol=1e-10)
     with pytest.raises(RuntimeError):
         state.accept()
+    # second half of the sampler step (bark_sampler.py:266-272): new (noise, scale), inverse rebuilt on accept
+    new_noise, new_scale = 0.07, 0.9
+    K2 = new_scale * B.orc.forest_gram_matrix(forest, X, X, ft) + (1e-6 + new_noise) * np.eye(400)
+    K2_inv, K2_logdet = np.linalg.inv(K2), np.linalg.slogdet(K2)[1]
+    before = state.mll
+    got = state.propose_noise_scale(forest, new_noise, new_scale, X, ft)
+    assert np.isclose(got, B.orc.mll(K2_inv, K2_logdet, y), rtol=1e-9)
+    assert state.mll == before  # a proposal does not modify the state
+    state.accept()
+    assert np.isclose(state.mll, got, rtol=1e-10) and np.isclose(state.logdet, K2_logdet, rtol=1e-10)
+    assert np.allclose(state.K_inv.cpu().numpy(), K2_inv, rtol=1e-7, atol=1e-8)
+    # and tree proposals continue from the rebuilt state
+    cur_lv = np.sqrt(new_scale / m) * B.orc.get_leaf_vectors(forest[7], X, ft)
+    new_lv = np.sqrt(new_scale / m) * B.orc.get_leaf_vectors(fresh[7], X, ft)
+    inv1 = B.orc.low_rank_inv_update(K2_inv, cur_lv, subtract=True)
+    det1 = B.orc.low_rank_det_update(K2_inv, cur_lv, K2_logdet, subtract=True)
+    want = B.orc.mll(B.orc.low_rank_inv_update(inv1, new_lv), B.orc.low_rank_det_update(inv1, new_lv, det1), y)
+    assert np.isclose(state.propose_tree(forest[7], fresh[7], X, ft, new_scale, m), want, rtol=1e-9, atol=1e-9)
 
 
 def test_woodbury_large_against_oracle(B):
