@@ -638,18 +638,24 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(Mats p, int j, 
         }
 }
 
+constexpr int RED_ROWS = 8;  // rows of a 128 x 128 tile per panel_reduce_kernel workgroup (4 doubles per thread)
 __global__ __launch_bounds__(THREADS) void panel_reduce_kernel(Mats p, int j, int n_right, int n_tiles, int S,
                                                                const double *slabs) {
-    const int t = blockIdx.x, b = blockIdx.y;
+    const int t = blockIdx.x / (NB / RED_ROWS), part = blockIdx.x % (NB / RED_ROWS), b = blockIdx.y;
     const int rb = t < n_right ? j : j + 1, cb = t < n_right ? j + 1 + t : j + 1;
-    double *tile = p.A + (size_t)b * p.bstride + (size_t)rb * NB * p.ld + (size_t)cb * NB;
-    const double *slab = slabs + (size_t)((size_t)b * n_tiles + t) * S * NB * NB;
-    for (int e = threadIdx.x; e < NB * NB; e += THREADS) {
-        double sum = 0.0;
-        for (int s = 0; s < S; ++s) sum += slab[(size_t)s * NB * NB + e];
-        double *dst = tile + (size_t)(e >> 7) * p.ld + (e & (NB - 1));
-        *dst = *dst - sum;
+    const int e = part * RED_ROWS * NB + 4 * threadIdx.x;  // four consecutive entries of one tile row
+    const double *slab = slabs + (size_t)((size_t)b * n_tiles + t) * S * NB * NB + e;
+    f64x2 s0 = {0.0, 0.0}, s1 = {0.0, 0.0};
+#pragma unroll 4
+    for (int s = 0; s < S; ++s) {  // fixed order: bit-reproducible
+        const f64x2 *src = reinterpret_cast<const f64x2 *>(slab + (size_t)s * NB * NB);
+        s0 += src[0];
+        s1 += src[1];
     }
+    f64x2 *dst = reinterpret_cast<f64x2 *>(p.A + (size_t)b * p.bstride + ((size_t)rb * NB + (e >> 7)) * p.ld +
+                                       (size_t)cb * NB + (e & (NB - 1)));
+    dst[0] -= s0;
+    dst[1] -= s1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -776,20 +782,85 @@ __global__ void finish_mll_kernel(const double *accum, int Bc, int N, int includ
 }
 
 // mu[c] = sum_r V[r][c] z[r] ; var[c] = scale - sum_r V[r][c]^2      (V = U^-T K_Xx, candidate columns)
-__global__ void predict_reduce_kernel(Mats p, int N, int C, const double *scale, double *mu, double *var) {
-    const int b = blockIdx.y;
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double *V = p.A + (size_t)b * p.bstride + (size_t)p.nrb * NB + c;
+// mu[c] = sum_r V[r][c] z[r],  var[c] = scale - sum_r V[r][c]^2  (or the plain sum of squares without `scale`:
+// identity right-hand side, diag(K_s^-1) = colsumsq(U^-T)) over the candidate block V of the factorised matrix.
+// A workgroup owns 64 columns (one 512-byte row segment per wave load); its four waves take interleaved rows,
+// eight in flight each, and are summed through LDS in wave order.  grid.z > 1 splits the rows into segments whose
+// partial sums go to `part` ([segment][matrix][column][2]) for predict_finish_kernel — used when columns x
+// matrices alone cannot fill the chip.
+constexpr int PR_UNROLL = 8;
+__global__ __launch_bounds__(256) void predict_reduce_kernel(Mats p, int N, int C, const double *scale, double *mu,
+                                                             double *var, double *part) {
+    __shared__ double red[2][4][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y, c = blockIdx.x * 64 + lane;
+    const int nseg = gridDim.z, seg = blockIdx.z;
+    const int rows_per = ((N + nseg - 1) / nseg + 3) & ~3;
+    const int r_begin = seg * rows_per, r_end = min(N, r_begin + rows_per);
+    const bool live = c < C;
+    const double *V = p.A + (size_t)b * p.bstride + (size_t)p.nrb * NB + (live ? c : 0);
     const double *z = p.yz + (size_t)b * p.nrb * NB;
     double m = 0.0, s2 = 0.0;
-    for (int r = 0; r < N; ++r) {
-        const double v = V[(size_t)r * p.ld];
-        m = fma(v, z[r], m);
-        s2 = fma(v, v, s2);
+    for (int r0 = r_begin + wave * PR_UNROLL; r0 < r_end; r0 += 4 * PR_UNROLL) {
+        double v[PR_UNROLL];
+#pragma unroll
+        for (int u = 0; u < PR_UNROLL; ++u) v[u] = (live && r0 + u < r_end) ? V[(size_t)(r0 + u) * p.ld] : 0.0;
+#pragma unroll
+        for (int u = 0; u < PR_UNROLL; ++u) {
+            m = fma(v[u], z[min(r0 + u, N - 1)], m);  // wave-uniform address
+            s2 = fma(v[u], v[u], s2);
+        }
+    }
+    red[0][wave][lane] = m;
+    red[1][wave][lane] = s2;
+    __syncthreads();
+    if (threadIdx.x >= 64 || !live) return;
+    m = ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane];
+    s2 = ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane];
+    if (nseg > 1) {
+        double *dst = part + (((size_t)seg * gridDim.y + b) * C + c) * 2;
+        dst[0] = m;
+        dst[1] = s2;
+        return;
     }
     mu[(size_t)b * C + c] = m;
-    if (var) var[(size_t)b * C + c] = scale ? scale[b] - s2 : s2;  // identity rhs: diag(K_s^-1) = colsumsq(U^-T)
+    if (var) var[(size_t)b * C + c] = scale ? scale[b] - s2 : s2;
+}
+
+__global__ void predict_finish_kernel(const double *part, int nseg, int Bc, int C, const double *scale, double *mu,
+                                      double *var) {
+    const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double m = 0.0, s2 = 0.0;
+    for (int sg = 0; sg < nseg; ++sg) {  // fixed order
+        const double *src = part + (((size_t)sg * Bc + b) * C + c) * 2;
+        m += src[0];
+        s2 += src[1];
+    }
+    mu[(size_t)b * C + c] = m;
+    if (var) var[(size_t)b * C + c] = scale ? scale[b] - s2 : s2;
+}
+
+// `scratch` (the split-K slab area, idle after the sweep) may be null: then rows are never segmented
+static int launch_predict_reduce(const Mats &p, int N, int C, int bc, const double *scale, double *mu, double *var,
+                                 double *scratch, hipStream_t s) {
+    const int col_groups = (C + 63) / 64;
+    int nseg = 1;
+    if (scratch && col_groups * bc < 512) {
+        nseg = 1024 / (col_groups * bc);
+        if (nseg > 16) nseg = 16;
+        if (nseg > N / 256) nseg = N / 256;
+        if (nseg < 1) nseg = 1;
+    }
+    hipLaunchKernelGGL(predict_reduce_kernel, dim3((unsigned)col_groups, (unsigned)bc, (unsigned)nseg), dim3(256), 0, s, p, N, C,
+                       scale, mu, var, scratch);
+    BARK_LAUNCH_CHECK();
+    if (nseg > 1) {
+        hipLaunchKernelGGL(predict_finish_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)bc), dim3(256), 0, s, scratch, nseg,
+                           bc, C, scale, mu, var);
+        BARK_LAUNCH_CHECK();
+    }
+    return BARK_OK;
 }
 
 // y' K_inv y  (quick_inverse.py:38), one workgroup, grid-stride rows
@@ -982,8 +1053,8 @@ struct Sweep {
                 hipLaunchKernelGGL(panel_split_kernel, dim3(xcd_grid(n_tiles * S, bc)), dim3(THREADS), GEMM_LDS, ps, p, j,
                                    n_right, n_tiles, S, slabs);
                 BARK_LAUNCH_CHECK();
-                hipLaunchKernelGGL(panel_reduce_kernel, dim3((unsigned)n_tiles, (unsigned)bc), dim3(THREADS), 0, ps, p, j,
-                                   n_right, n_tiles, S, slabs);
+                hipLaunchKernelGGL(panel_reduce_kernel, dim3((unsigned)(n_tiles * (NB / RED_ROWS)), (unsigned)bc), dim3(THREADS),
+                                   0, ps, p, j, n_right, n_tiles, S, slabs);
             } else if (!fused)
                 hipLaunchKernelGGL(panel_kernel<0>, pg, dim3(THREADS), pl, ps, p, j, n_right, n_tiles);
             else if (rep == REP_BITS)
@@ -1176,11 +1247,10 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
                            (flags & BARK_MLL_INCLUDE_2PI) ? 1 : 0, mll_out + c0);
         BARK_LAUNCH_CHECK();
         if (C > 0) {
-            dim3 g((unsigned)((C + 255) / 256), (unsigned)bc);
-            hipLaunchKernelGGL(predict_reduce_kernel, g, dim3(256), 0, s, p, (int)N, (int)C,
-                               rhs_identity ? nullptr : scale + c0, mu_out + (size_t)c0 * C,
-                               var_out ? var_out + (size_t)c0 * C : nullptr);
-            BARK_LAUNCH_CHECK();
+            const int prc = launch_predict_reduce(p, (int)N, (int)C, (int)bc, rhs_identity ? nullptr : scale + c0,
+                                                  mu_out + (size_t)c0 * C, var_out ? var_out + (size_t)c0 * C : nullptr,
+                                                  L.splitk ? sw.slabs : nullptr, s);
+            if (prc) return prc;
             if (cov_out) {
                 const int nct = (int)(L.cpad / NB);
                 hipLaunchKernelGGL(vtv_kernel, dim3(xcd_grid(nct * nct, (int)bc)), dim3(THREADS), GEMM_LDS, s, p, nct,
@@ -1351,9 +1421,8 @@ static int leafspace_run(const void *packed, const bark_pack_info *info, const d
         if (want_minv) {
             // w = M^-1 v = V'z and M^-1 = V'V (the same kernels the dense posterior / inverse export use)
             const int R = (int)g.R;
-            hipLaunchKernelGGL(predict_reduce_kernel, dim3((unsigned)((R + 255) / 256), (unsigned)bc), dim3(256), 0, caller, p, R,
-                               R, (const double *)nullptr, wvec, (double *)nullptr);
-            BARK_LAUNCH_CHECK();
+            if ((rc = launch_predict_reduce(p, R, R, (int)bc, nullptr, wvec, nullptr, g.L.splitk ? sw.slabs : nullptr, caller)))
+                return rc;
             const int nct = (int)(g.L.cpad / NB);
             hipLaunchKernelGGL(vtv_kernel, dim3(xcd_grid(nct * nct, (int)bc)), dim3(THREADS), GEMM_LDS, caller, p, nct, R,
                                (const double *)nullptr, 1.0, 1, Minv);

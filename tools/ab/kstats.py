@@ -13,4 +13,4 @@ q = f"select s.kernel_name, count(*), avg(d.end-d.start)/1e3 from {kd} d join {k
 for name, n, avg in c.execute(q):
     if not pats or any(p in name for p in pats):
         short = name.split("_GLOBAL__N_1")[-1][:40]
-        print(f"   {short:40s} n={n:5d} avg={avg:8.2f} us")
+        print(f"   {short:40s} n={n:5d} avg={avg:9.2f} us  total={n * avg / 1e3:9.3f} ms")
