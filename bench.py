@@ -200,6 +200,43 @@ def main():
                       "max_rel_diff_vs_dense": float(np.max(np.abs(leaf_local - dense_local) / np.abs(dense_local)))}
         del lws
 
+    # one chain of the sampler on this workload's data: per-tree proposal, accept, noise/scale
+    # proposal and the rebuild of the resident inverse — secondary numbers, never `value`
+    chain_probe = None
+    if rank == 0:
+        from bark_amd.fitting import ChainState
+
+        def wall_ms(fn, reps):
+            fn()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / reps * 1e3
+
+        chain = ChainState.from_forest(forests[0], float(noise[0]), 1.0, Xd, y, ft)
+        old_tree, new_tree = forests[0][0], forests[1][0]
+
+        def swap_there_and_back():
+            chain.propose_tree(old_tree, new_tree, Xd, ft, 1.0, m)
+            chain.accept()
+            chain.propose_tree(new_tree, old_tree, Xd, ft, 1.0, m)
+            chain.accept()
+
+        def rebuild():
+            chain.propose_noise_scale(forests[0], float(noise[0]), 1.0, Xd, ft)
+            chain.accept()
+
+        t_prop = wall_ms(lambda: chain.propose_tree(old_tree, new_tree, Xd, ft, 1.0, m), 50)
+        t_pair = wall_ms(swap_there_and_back, 25) / 2
+        t_ns = wall_ms(lambda: chain.propose_noise_scale(forests[0], float(noise[0]), 1.0, Xd, ft), 20)
+        t_rebuild = wall_ms(rebuild, 10)
+        chain_probe = {"note": "one chain, N=%d, m=%d, wall time per call incl. host (bark_sampler.py:226-272)" % (N, m),
+                       "tree_proposal_ms": t_prop, "tree_proposal_plus_accept_ms": t_pair,
+                       "noise_scale_proposal_ms": t_ns, "noise_scale_proposal_plus_rebuild_ms": t_rebuild}
+        del chain
+
     steps = args.steps
     evals = B * world * steps
     value = evals / elapsed
@@ -257,6 +294,7 @@ def main():
             "gram_kernel": gram_probe,
         },
         "leafspace_probe": leaf_probe,
+        "chain_step_probe": chain_probe,
     }
 
     if rank == 0 and world == 1 and args.cpu_sample > 0:
