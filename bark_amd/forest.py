@@ -3,7 +3,7 @@
 Same names, argument order, shapes and dtypes as the reference module:
 
     NODE_RECORD_DTYPE, FeatureTypeEnum, create_empty_forest,
-    pass_through_tree, pass_through_forest, get_leaf_vectors,
+    _pass_one_through_tree, pass_through_tree, pass_through_forest, get_leaf_vectors,
     forest_gram_matrix, batched_forest_gram_matrix, batched_forest_gram_matrix_no_null
 
 numpy in -> numpy out (host round trip over PCIe), or pass `torch` CUDA tensors for the
@@ -226,6 +226,13 @@ def pass_through_tree(nodes, X, feat_types):
         raise ValueError(f"nodes must be (node_limit,), got {nodes.shape}")
     out = pass_through_forest(nodes[None], X, feat_types)
     return out[:, 0].copy() if isinstance(out, np.ndarray) else out[:, 0].contiguous()
+
+
+def _pass_one_through_tree(nodes, X, feat_types):
+    """forest.py:28-47 -> index of the leaf ONE point X (d,) reaches in one tree (a Python int for numpy input)."""
+    if _is_torch(X):
+        return pass_through_tree(nodes, X.reshape(1, -1), feat_types)[0]
+    return int(pass_through_tree(nodes, np.asarray(X, dtype=np.float64).reshape(1, -1), feat_types)[0])
 
 
 def get_leaf_vectors(nodes, X, feat_types):

@@ -1,1 +1,1 @@
-from .tree_gps import forest_predict, mixture_of_gaussians_as_normal  # noqa: F401
+from .tree_gps import BARKModel, forest_predict, mixture_of_gaussians_as_normal  # noqa: F401

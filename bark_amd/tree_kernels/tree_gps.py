@@ -10,11 +10,22 @@ the reference are out of scope.
 
 from __future__ import annotations
 
+from typing import NamedTuple
+
 import numpy as np
 
 from .. import _lib
 from ..fitting.mll import _feat_types_of, _run, _run_leafspace
 from ..forest import _is_torch
+
+
+class BARKModel(NamedTuple):
+    """tree_gps.py:14-17 — the (forest, noise, scale) triple `forest_predict` and `mll` take; leading dims
+    (chains, samples) of all three are flattened by the callees."""
+
+    forest: np.ndarray
+    noise: np.ndarray
+    scale: np.ndarray
 
 
 def forest_predict(model, data, candidates, domain, diag: bool = True, method: str = "dense"):

@@ -45,6 +45,8 @@ def test_g1_kat_tree(B):
     leaves = B.bf.pass_through_forest(nodes, g["x"], g["feat_types"])
     assert leaves.dtype == np.uint32 and leaves.shape == (20, 1) and np.array_equal(leaves, g["leaves"])
     assert np.array_equal(B.bf.pass_through_tree(nodes[0], g["x"], g["feat_types"]), g["leaves"][:, 0])
+    for i in (0, 7, 19):  # the single-point walk of forest.py:28-47
+        assert B.bf._pass_one_through_tree(nodes[0], g["x"][i], g["feat_types"]) == int(g["leaves"][i, 0])
     K = B.bf.forest_gram_matrix(nodes, g["x"], g["x"], g["feat_types"])
     assert K.dtype == np.float64 and np.array_equal(K, g["K"])
     assert np.array_equal(B.bf.get_leaf_vectors(nodes[0], g["x"], g["feat_types"]), g["leaf_vectors"])

@@ -150,7 +150,7 @@ def test_reference_api_surface():
     import bark_amd.tree_kernels as tk
     from bark_amd.tree_kernels.tree_model_kernel import TreeAgreementKernel  # noqa: F401
 
-    for n in ("NODE_RECORD_DTYPE", "FeatureTypeEnum", "create_empty_forest", "pass_through_tree",
+    for n in ("NODE_RECORD_DTYPE", "FeatureTypeEnum", "create_empty_forest", "_pass_one_through_tree", "pass_through_tree",
               "pass_through_forest", "get_leaf_vectors", "forest_gram_matrix", "batched_forest_gram_matrix",
               "batched_forest_gram_matrix_no_null"):
         assert hasattr(bf, n)
@@ -163,6 +163,10 @@ def test_reference_api_surface():
     assert _lib.lib().bark_lowrank_workspace_bytes(4096, 65) == 0
     assert hasattr(fit, "mll") and hasattr(fit, "batched_mll")
     assert hasattr(tk, "forest_predict") and hasattr(tk, "mixture_of_gaussians_as_normal")
+    model = tk.BARKModel(bf.create_empty_forest(2, 4)[None], np.array([0.1]), np.array([1.0]))  # tree_gps.py:14-17
+    assert model._fields == ("forest", "noise", "scale") and model[1][0] == 0.1
+    for n in ("ChainState", "batched_kernel_inverse"):
+        assert hasattr(fit, n)
     g = load_golden("g6_predict")
     mix_mu, mix_var = tk.mixture_of_gaussians_as_normal(g["mu"], g["var"])
     assert np.allclose(mix_mu, g["mix_mu"]) and np.allclose(mix_var, g["mix_var"])
