@@ -5,8 +5,11 @@
 // (first two inactive slots, src/bark/fitting/tree_proposals.py:46-58,147-165) and pruned
 // sub-trees stay behind as garbage.  The device wants the few live nodes of each tree,
 // aligned, with validated child links (a GPU walk must never leave the container or spin).
+#include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -58,8 +61,9 @@ struct TreeStats {
 };
 
 // Depth-first walk from the root.  `out` (may be null) receives 4 uint32 per compact node.
+// `cap` (with `out`): number of 16-byte slots `out` holds; a tree with more live nodes is an error, never an overrun.
 int pack_tree(const uint8_t *tree, int64_t L, const int64_t *feat_types, int64_t d, Scratch &s, uint32_t *out,
-              TreeStats *stats, int64_t b, int64_t t, uint32_t bit_base = 0) {
+              TreeStats *stats, int64_t b, int64_t t, uint32_t bit_base = 0, int64_t cap = 0) {
     s.cidx.assign((size_t)L, -1);
     s.colour.assign((size_t)L, 0);
     s.stack_node.clear();
@@ -67,6 +71,7 @@ int pack_tree(const uint8_t *tree, int64_t L, const int64_t *feat_types, int64_t
     int64_t n_nodes = 0, n_leaves = 0, max_depth = 0;
 
     auto discover = [&](uint32_t orig) -> int {
+        if (out && n_nodes >= cap) return 1;
         s.cidx[orig] = (int32_t)n_nodes++;
         s.colour[orig] = 1;
         s.stack_node.push_back(orig);
@@ -75,7 +80,7 @@ int pack_tree(const uint8_t *tree, int64_t L, const int64_t *feat_types, int64_t
         if (depth > max_depth) max_depth = depth;
         return 0;
     };
-    discover(0);
+    if (discover(0)) return fail(BARK_ERR_ARG, "bark_forest_pack: info does not match forest");
 
     while (!s.stack_node.empty()) {
         uint32_t orig = s.stack_node.back();
@@ -131,7 +136,8 @@ int pack_tree(const uint8_t *tree, int64_t L, const int64_t *feat_types, int64_t
             if (s.colour[child] == 1)
                 return fail(BARK_ERR_TREE, "forest %lld tree %lld: cycle through node %u", (long long)b, (long long)t,
                             child);
-            if (s.colour[child] == 0) discover(child);
+            if (s.colour[child] == 0 && discover(child))
+                return fail(BARK_ERR_ARG, "bark_forest_pack: info does not match forest");
             if (slot) slot[2 + phase] = (uint32_t)s.cidx[child];
             continue;
         }
@@ -142,6 +148,31 @@ int pack_tree(const uint8_t *tree, int64_t L, const int64_t *feat_types, int64_t
     stats->nodes = n_nodes;
     stats->leaves = n_leaves;
     stats->depth = max_depth;
+    return BARK_OK;
+}
+
+// Forests are independent: run `fn(b_begin, b_end)` over contiguous ranges on a few host threads (the sampler
+// hands over hundreds of forests; one thread packs ~1 us per tree).  The error of the lowest failing range wins
+// and is copied into the CALLER's thread-local message buffer.
+template <class Fn>
+int for_forest_ranges(int64_t B, Fn fn) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int64_t want = std::min<int64_t>({(int64_t)(hw ? hw : 1), 8, B / 16});
+    if (want <= 1) return fn(0, B);
+    const int64_t T = want, per = (B + T - 1) / T;
+    std::vector<int> rc((size_t)T, BARK_OK);
+    std::vector<std::string> msg((size_t)T);
+    std::vector<std::thread> pool;
+    for (int64_t k = 0; k < T; ++k)
+        pool.emplace_back([&, k] {
+            const int64_t b0 = k * per, b1 = std::min(B, b0 + per);
+            if (b0 >= b1) return;
+            rc[(size_t)k] = fn(b0, b1);
+            if (rc[(size_t)k]) msg[(size_t)k] = error_buffer();  // this worker's thread-local buffer
+        });
+    for (auto &t : pool) t.join();
+    for (int64_t k = 0; k < T; ++k)
+        if (rc[(size_t)k]) return fail(rc[(size_t)k], "%s", msg[(size_t)k].c_str());
     return BARK_OK;
 }
 
@@ -163,20 +194,35 @@ int bark_forest_pack_info(const void *nodes26, int64_t B, int64_t m, int64_t L, 
         return fail(BARK_ERR_ARG, "bark_forest_pack_info: bad argument (B=%lld m=%lld L=%lld d=%lld)", (long long)B,
                     (long long)m, (long long)L, (long long)d);
     const uint8_t *base = static_cast<const uint8_t *>(nodes26);
-    Scratch s;
-    int64_t stride = 1, max_leaves = 1, max_depth = 0, max_bits = 1;
-    for (int64_t b = 0; b < B; ++b) {
-        int64_t bits = 0;
-        for (int64_t t = 0; t < m; ++t) {
-            TreeStats st;
-            int rc = pack_tree(base + ((size_t)b * m + t) * L * NODE_BYTES, L, feat_types, d, s, nullptr, &st, b, t);
-            if (rc) return rc;
-            if (st.nodes > stride) stride = st.nodes;
-            if (st.leaves > max_leaves) max_leaves = st.leaves;
-            if (st.depth > max_depth) max_depth = st.depth;
-            bits += st.leaves;
+    struct Extent {
+        int64_t stride = 1, max_leaves = 1, max_depth = 0, max_bits = 1;
+    };
+    std::vector<Extent> per_forest((size_t)B);
+    int rc_all = for_forest_ranges(B, [&](int64_t b0, int64_t b1) -> int {
+        Scratch s;
+        for (int64_t b = b0; b < b1; ++b) {
+            Extent &e = per_forest[(size_t)b];
+            int64_t bits = 0;
+            for (int64_t t = 0; t < m; ++t) {
+                TreeStats st;
+                int rc = pack_tree(base + ((size_t)b * m + t) * L * NODE_BYTES, L, feat_types, d, s, nullptr, &st, b, t);
+                if (rc) return rc;
+                e.stride = std::max(e.stride, st.nodes);
+                e.max_leaves = std::max(e.max_leaves, st.leaves);
+                e.max_depth = std::max(e.max_depth, st.depth);
+                bits += st.leaves;
+            }
+            e.max_bits = std::max(e.max_bits, bits);
         }
-        if (bits > max_bits) max_bits = bits;
+        return BARK_OK;
+    });
+    if (rc_all) return rc_all;
+    int64_t stride = 1, max_leaves = 1, max_depth = 0, max_bits = 1;
+    for (const Extent &e : per_forest) {
+        stride = std::max(stride, e.stride);
+        max_leaves = std::max(max_leaves, e.max_leaves);
+        max_depth = std::max(max_depth, e.max_depth);
+        max_bits = std::max(max_bits, e.max_bits);
     }
     info->B = B;
     info->m = m;
@@ -196,26 +242,29 @@ int bark_forest_pack(const void *nodes26, const int64_t *feat_types, int64_t d, 
     const uint8_t *base = static_cast<const uint8_t *>(nodes26);
     uint32_t *out = static_cast<uint32_t *>(packed);
     const int64_t B = info->B, m = info->m, L = info->L, stride = info->stride;
-    Scratch s;
-    for (int64_t b = 0; b < B; ++b) {
-        uint32_t bit_base = 0;  // trees of a forest own consecutive bit fields
-        for (int64_t t = 0; t < m; ++t) {
-            uint32_t *dst = out + ((size_t)b * m + t) * stride * 4;
-            // unused tail slots: self-looping leaves (never reached, but harmless if they were)
-            for (int64_t k = 0; k < stride; ++k) {
-                dst[k * 4 + 0] = LEAF_FLAG;
-                dst[k * 4 + 1] = 0;
-                dst[k * 4 + 2] = dst[k * 4 + 3] = (uint32_t)k;
+    if (B < 1 || m < 1 || L < 1 || stride < 1) return fail(BARK_ERR_ARG, "bark_forest_pack: bad info");
+    return for_forest_ranges(B, [&](int64_t b0, int64_t b1) -> int {
+        Scratch s;
+        for (int64_t b = b0; b < b1; ++b) {
+            uint32_t bit_base = 0;  // trees of a forest own consecutive bit fields
+            for (int64_t t = 0; t < m; ++t) {
+                uint32_t *dst = out + ((size_t)b * m + t) * stride * 4;
+                // unused tail slots: self-looping leaves (never reached, but harmless if they were)
+                for (int64_t k = 0; k < stride; ++k) {
+                    dst[k * 4 + 0] = LEAF_FLAG;
+                    dst[k * 4 + 1] = 0;
+                    dst[k * 4 + 2] = dst[k * 4 + 3] = (uint32_t)k;
+                }
+                TreeStats st;
+                int rc = pack_tree(base + ((size_t)b * m + t) * L * NODE_BYTES, L, feat_types, d, s, dst, &st, b, t, bit_base,
+                                   stride);
+                if (rc) return rc;
+                bit_base += (uint32_t)st.leaves;
             }
-            TreeStats st;
-            int rc = pack_tree(base + ((size_t)b * m + t) * L * NODE_BYTES, L, feat_types, d, s, dst, &st, b, t, bit_base);
-            if (rc) return rc;
-            if (st.nodes > stride) return fail(BARK_ERR_ARG, "bark_forest_pack: info does not match forest");
-            bit_base += (uint32_t)st.leaves;
+            if ((int64_t)bit_base > info->max_bits) return fail(BARK_ERR_ARG, "bark_forest_pack: info does not match forest");
         }
-        if ((int64_t)bit_base > info->max_bits) return fail(BARK_ERR_ARG, "bark_forest_pack: info does not match forest");
-    }
-    return BARK_OK;
+        return BARK_OK;
+    });
 }
 
 }  // extern "C"

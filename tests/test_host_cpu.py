@@ -127,6 +127,21 @@ def test_packer_rejects_malformed_trees():
         host_pack(_tree([(0, 5, 0.5, 1, 2, 0, 0, 1), (1, 0, 0, 0, 0, 0, 1, 1), (1, 0, 0, 0, 0, 0, 1, 1)]), ft)
     with pytest.raises(ValueError, match="bitmask"):
         host_pack(_tree([(0, 1, -3.0, 1, 2, 0, 0, 1), (1, 0, 0, 0, 0, 0, 1, 1), (1, 0, 0, 0, 0, 0, 1, 1)]), ft)
+    # many forests are packed on several host threads: same result as one by one, and the error of a bad
+    # forest reaches the caller's message buffer with its index
+    many = np.repeat(ok, 96, axis=0)
+    info, packed = host_pack(many, ft)
+    assert info.B == 96 and np.array_equal(packed[0], packed[95]) and np.array_equal(packed[0], host_pack(ok, ft)[1][0])
+    many[70] = _tree([(0, 0, 0.5, 1, 9, 0, 0, 1), (1, 0, 0, 0, 0, 0, 1, 1)])[0]
+    with pytest.raises(ValueError, match="forest 70 .*outside container"):
+        host_pack(many, ft)
+    # a forest that does not fit the info it is packed with is an error, not an overrun
+    small_info, _ = host_pack(_tree([(1, 0, 0.5, 0, 0, 0, 0, 1)]), ft)
+    buf = np.zeros(small_info.packed_bytes // 4, dtype=np.uint32)
+    ft64 = np.ascontiguousarray(ft, dtype=np.int64)
+    with pytest.raises(ValueError, match="does not match"):
+        _lib.check(_lib.lib().bark_forest_pack(_lib.ptr(np.ascontiguousarray(ok)), _lib.ptr(ft64), 2, ctypes.byref(small_info),
+                                               _lib.ptr(buf)))
     # pruned garbage behind a leaf is ignored (tree_proposals.py:168-175 leaves children in place)
     pruned = _tree([(1, 0, 0.5, 7, 7, 0, 0, 1)])
     info, packed = host_pack(pruned, ft)
