@@ -216,7 +216,7 @@ def main():
             return (time.perf_counter() - t) / reps * 1e3
 
         chain = ChainState.from_forest(forests[0], float(noise[0]), 1.0, Xd, y, ft)
-        old_tree, new_tree = forests[0][0], forests[1][0]
+        old_tree, new_tree = forests[0][0], forests[-1][-1]  # any two trees of this rank's forests
 
         def swap_there_and_back():
             chain.propose_tree(old_tree, new_tree, Xd, ft, 1.0, m)
