@@ -369,7 +369,6 @@ __device__ __forceinline__ void factor16(double *blk, int lane, int base_index, 
             if (!bad) bad = base_index + k + 1;
             d = 1.0;
         }
-        logsum += 0.5 * log(d);
         const double rd = 1.0 / d;
         const double lc = __shfl(e[kv], kl + c);  // D[k][c]
         const double rc = __shfl(f[kv], kl + c);  // I[k][c]
@@ -382,6 +381,23 @@ __device__ __forceinline__ void factor16(double *blk, int lane, int base_index, 
                 f[v] = fma(-m, rc, f[v]);
             }
         }
+    }
+    // log|D| from the 16 frozen pivots, one per lane and in parallel (a serial log per elimination step costs
+    // ~3 us per call on the one wave every other wave is waiting for): pivot r sits in register r >> 2 of lane
+    // (r & 3, r).  Lanes 0..15 end up with the block's sum; the caller reads lane 0's.
+    {
+        const int r = lane & 15;
+        double piv = 1.0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const double dv = __shfl(e[v], (r & 3) * 16 + r);
+            if ((r >> 2) == v) piv = dv;
+        }
+        if (!(piv > 0.0)) piv = 1.0;
+        double lg = log(piv);
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) lg += __shfl_xor(lg, off);
+        logsum += 0.5 * lg;
     }
     // row r of the right half is (L~^-1)[r][:]; U^-T = diag(1/sqrt d) L~^-1, so W[c][r] = f * rsqrt(d_r)
 #pragma unroll
@@ -400,6 +416,12 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j) {
     const int wave = tid >> 6, lane = tid & 63;
     double *Ab = p.A + (size_t)b * p.bstride;
     double *tile = Ab + (size_t)j * NB * p.ld + (size_t)j * NB;
+    // operands of the kernel's last phase, requested now so their latency hides behind the factorisation
+    // (solve_kernel(j-1) finished updating y_j before this launch)
+    const double y_in = tid < NB ? p.yz[(size_t)b * p.nrb * NB + (size_t)j * NB + tid] : 0.0;
+    const double acc_quad = tid == 0 ? p.accum[(size_t)b * 2 + 0] : 0.0;
+    const double acc_logdet = tid == 0 ? p.accum[(size_t)b * 2 + 1] : 0.0;
+    const int info_in = tid == 0 ? p.info[b] : 0;
 
     f64x4 acc[4][4];
     zero_acc(acc);
@@ -409,8 +431,8 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j) {
     }
     double *S = lds;                                          // packed upper block triangle, NBLK x [16][16]
     double *scratch = lds + NBLK * SB * SB + wave * SB * TS;  // per-wave [16][TS]
-    double *vec = lds + NBLK * SB * SB + 4 * SB * TS;         // [128] y / partial sums
-    double *red = vec + NB;                                   // [8]
+    double *vec = lds + NBLK * SB * SB + 4 * SB * TS;         // [2][128] y | upper-half partial sums
+    double *red = vec + 2 * NB;                               // [8]
     // D = P - U[j-1,j]'U[j-1,j]: only sub-blocks on or above the block diagonal are kept
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -493,24 +515,37 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j) {
     }
 
     // --- z_j = W_j' y_j ; quad += |z_j|^2 ; logdet += 2 sum log u_kk ----------------------------
+    // thread (c, half) sums rows half*64 .. half*64+63 of column c (rows <= c only: W_j is upper triangular);
+    // fixed trip count, so the LDS reads pipeline.  y_j and the accumulators were loaded at kernel entry.
     double *yb = p.yz + (size_t)b * p.nrb * NB + (size_t)j * NB;
-    if (tid < NB) vec[tid] = yb[tid];
+    if (tid < NB) vec[tid] = y_in;
     __syncthreads();
-    double zz = 0.0;
-    if (tid < NB) {
-        double z = 0.0;
-        for (int r = 0; r <= tid; ++r) z = fma(s_at(S, r, tid), vec[r], z);
-        yb[tid] = z;
-        zz = z * z;
-    }
+    {
+        const int c = tid & (NB - 1), half = tid >> 7;
+        double part = 0.0;
+#pragma unroll 8
+        for (int i = 0; i < NB / 2; ++i) {
+            const int r = half * (NB / 2) + i;
+            const double w = s_at(S, min(r, c), c);
+            part = fma(r <= c ? w : 0.0, vec[r], part);
+        }
+        if (half) vec[NB + c] = part;  // vec has 2 * NB doubles
+        __syncthreads();
+        double zz = 0.0;
+        if (!half) {
+            const double z = part + vec[NB + c];
+            yb[c] = z;
+            zz = z * z;
+        }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) zz += __shfl_xor(zz, off);
-    if (lane == 0) red[wave] = zz;
+        for (int off = 32; off > 0; off >>= 1) zz += __shfl_xor(zz, off);
+        if (lane == 0) red[wave] = zz;
+    }
     __syncthreads();
     if (tid == 0) {  // wave 0 ran factor16: its logsum / bad are the matrix's
-        p.accum[(size_t)b * 2 + 0] += red[0] + red[1];
-        p.accum[(size_t)b * 2 + 1] += 2.0 * logsum;
-        if (bad && p.info[b] == 0) p.info[b] = j * NB + bad;
+        p.accum[(size_t)b * 2 + 0] = acc_quad + (red[0] + red[1]);
+        p.accum[(size_t)b * 2 + 1] = acc_logdet + 2.0 * logsum;
+        if (bad && info_in == 0) p.info[b] = j * NB + bad;
     }
 }
 
@@ -918,7 +953,7 @@ Layout make_layout(int64_t N, int64_t C, int64_t m, int64_t Bc) {
     return L;
 }
 
-constexpr size_t DIAG_LDS = (size_t)(NBLK * SB * SB + 4 * SB * TS + NB + 8) * sizeof(double);
+constexpr size_t DIAG_LDS = (size_t)(NBLK * SB * SB + 4 * SB * TS + 2 * NB + 8) * sizeof(double);
 constexpr size_t GEMM_LDS = (size_t)GEMM_LDS_DOUBLES * sizeof(double);
 static_assert(DIAG_LDS >= GEMM_LDS, "diag kernel reuses its LDS for the K=128 GEMM stage");
 
