@@ -146,7 +146,7 @@ __global__ __launch_bounds__(LR_THREADS) void skinny_kernel(const double *__rest
             const int q = e / r;
             ur[e] = (row0 + q < N) ? U[(size_t)row0 * r + e] : 0.0;
         }
-        if (threadIdx.x < ROWS) yv[threadIdx.x] = (y && row0 + threadIdx.x < N) ? y[row0 + threadIdx.x] : 0.0;
+        if ((int)threadIdx.x < ROWS) yv[threadIdx.x] = (y && row0 + (int)threadIdx.x < N) ? y[row0 + threadIdx.x] : 0.0;
         __syncthreads();
         double *dst = partial + (size_t)blockIdx.x * (r * r + r);
         for (int e = threadIdx.x; e < r * r + r; e += LR_THREADS) {
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(LR_THREADS) void colsum_finish_kernel(const double 
         ur[e] = uv;
     }
     if (!partial) return;
-    if (threadIdx.x < ROWS) yv[threadIdx.x] = (y && threadIdx.x < rows) ? y[row0 + threadIdx.x] : 0.0;
+    if ((int)threadIdx.x < ROWS) yv[threadIdx.x] = (y && (int)threadIdx.x < rows) ? y[row0 + threadIdx.x] : 0.0;
     __syncthreads();
     double *dst = partial + (size_t)blockIdx.x * (r * r + r);
     for (int e = threadIdx.x; e < r * r + r; e += LR_THREADS) {
