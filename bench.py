@@ -324,6 +324,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
+        dist.barrier()  # rank 0 ran the untimed probes above; leave together
         dist.destroy_process_group()
 
 
