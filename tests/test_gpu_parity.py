@@ -229,6 +229,82 @@ def test_deep_trees_and_many_leaves(B):
         assert np.allclose(got, want, rtol=MLL_RTOL, atol=MLL_ATOL)
 
 
+def _scrambled_forest(rng, m, L, ft, max_leaves):
+    """Random tree topologies placed in arbitrary container slots (as tree_proposals.py:46-58 leaves them after
+    grow/prune cycles), unused slots filled with garbage records, thresholds of every feature type."""
+    from bark_amd.forest import NODE_RECORD_DTYPE
+
+    d = len(ft)
+    forest = np.zeros((m, L), dtype=NODE_RECORD_DTYPE)
+    for t in range(m):
+        tree = forest[t]
+        # garbage everywhere first: never reachable from the root, must be ignored
+        tree["is_leaf"] = rng.integers(0, 2, L)
+        tree["feature_idx"] = rng.integers(0, 2**31, L)
+        tree["threshold"] = rng.standard_normal(L).astype(np.float32)
+        tree["left"] = rng.integers(0, 2**31, L)
+        tree["right"] = rng.integers(0, 2**31, L)
+        tree["active"] = 0
+        free = list(rng.permutation(np.arange(1, L)))
+        tree[0] = (1, 0, 0, 0, 0, 0xFFFFFFFF, 0, 1)
+        leaves = [0]
+        for _ in range(int(rng.integers(0, max_leaves))):
+            if len(free) < 2:
+                break
+            node = leaves.pop(int(rng.integers(len(leaves))))
+            f = int(rng.integers(d))
+            if ft[f] == 0:      # categorical: bitmask of categories as float32 (domain.py:31-34)
+                thr = float(rng.integers(0, 32))
+            elif ft[f] == 1:    # integer feature: x <= thr
+                thr = float(rng.integers(0, 10))
+            else:
+                thr = float(np.float32(rng.uniform()))
+            left, right = int(free.pop()), int(free.pop())
+            depth = int(tree[node]["depth"])
+            tree[node] = (0, f, thr, left, right, tree[node]["parent"], depth, 1)
+            tree[left] = (1, 0, 0, 0, 0, node, depth + 1, 1)
+            tree[right] = (1, 0, 0, 0, 0, node, depth + 1, 1)
+            leaves += [left, right]
+    return forest
+
+
+def test_fuzz_scrambled_containers_and_boundary_points(B):
+    """Seeded structural fuzz: leaves, Gram and no-null Gram bit-identical to the oracle for random topologies in
+    scrambled containers, with points planted exactly on thresholds and at +-inf / NaN / -0.0."""
+    rng = np.random.default_rng(2024)
+    ft = np.array([2, 2, 1, 0, 2, 0, 1, 2])
+    for case in range(12):
+        m = int(rng.integers(1, 23))
+        L = int(rng.choice([7, 16, 100, 255]))
+        forest = np.stack([_scrambled_forest(rng, m, L, ft, max_leaves=1 + case * 2) for _ in range(3)])
+        N, M = int(rng.integers(1, 300)), int(rng.integers(1, 200))
+
+        def points(n):
+            X = np.empty((n, 8))
+            for f, kind in enumerate(ft):
+                if kind == 0:
+                    X[:, f] = rng.integers(0, 5, n)
+                elif kind == 1:
+                    X[:, f] = rng.integers(0, 11, n)
+                else:
+                    X[:, f] = rng.uniform(size=n)
+            # plant continuous / integer values exactly on thresholds the forests use, and non-finite values
+            thr = forest["threshold"][forest["active"] == 1].astype(np.float64)
+            for f in (0, 1, 4, 7, 2, 6):
+                hit = rng.random(n) < 0.15
+                X[hit, f] = rng.choice(thr, hit.sum())
+                X[rng.random(n) < 0.02, f] = rng.choice([np.inf, -np.inf, np.nan, -0.0, np.nextafter(0.5, 1)])
+            return X
+
+        X1, X2 = points(N), points(M)
+        for b in range(3):
+            assert np.array_equal(B.bf.pass_through_forest(forest[b], X1, ft), B.orc.pass_through_forest(forest[b], X1, ft))
+        assert np.array_equal(B.bf.batched_forest_gram_matrix(forest, X1, X2, ft),
+                              B.orc.batched_forest_gram_matrix(forest, X1, X2, ft)), case
+        assert np.array_equal(B.bf.batched_forest_gram_matrix_no_null(forest, X1, X1, ft),
+                              B.orc.batched_forest_gram_matrix_no_null(forest, X1, X1, ft)), case
+
+
 def test_wide_feature_matrix_walks_from_global_memory(B):
     """d = 40 > 31: the point rows no longer fit the walk kernel's LDS tile (leaf_walk_kernel<., false>)."""
     rng = np.random.default_rng(40)
