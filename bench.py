@@ -279,12 +279,12 @@ def main():
             "panel_kernel": {
                 "launches_per_step": int(timing.n_panel_launches),
                 "avg_ms": per_step["panel_ms"] / max(int(timing.n_panel_launches), 1),
-                "executed_tflops": timing.panel_flops / (per_step["panel_ms"] * 1e-3) / 1e12,
+                "executed_tflops": timing.panel_flops / (max(per_step["panel_ms"], 1e-9) * 1e-3) / 1e12,
             },
             "solve_kernel": {
                 "launches_per_step": int(timing.n_solve_launches),
                 "avg_ms": per_step["solve_ms"] / max(int(timing.n_solve_launches), 1),
-                "executed_tflops": timing.solve_flops / (per_step["solve_ms"] * 1e-3) / 1e12,
+                "executed_tflops": timing.solve_flops / (max(per_step["solve_ms"], 1e-9) * 1e-3) / 1e12,
             },
             "diag_kernel": {
                 "launches_per_step": int(timing.n_diag_launches),
