@@ -37,12 +37,13 @@ def _feat_types_of(domain_or_feat_types):
         raise TypeError("pass feat_types (int array: 0=Cat, 1=Int, 2=Cont) or a bofire Domain") from exc
 
 
-def choose_chunk(B: int, N: int, C: int, m: int, budget_bytes: int | None = None) -> int:
-    """How many forests to factorise concurrently: as many as fit the HBM budget (default 70 % of
-    the free device memory, or $BARK_WORKSPACE_GB)."""
+def _fit_chunk(B: int, need, budget_bytes: int | None = None) -> int:
+    """Largest chunk of forests whose workspace `need(chunk)` (monotone) fits the HBM budget: default 70 % of the
+    free device memory (counting the cached workspace as free), or $BARK_WORKSPACE_GB."""
     import torch
 
-    lib = _lib.lib()
+    if budget_bytes is None and need(B) <= (256 << 20):
+        return int(B)  # small enough not to ask the driver (a latency-sensitive caller may be in a sampler loop)
     if budget_bytes is None:
         env = os.environ.get("BARK_WORKSPACE_GB")
         if env:
@@ -51,10 +52,9 @@ def choose_chunk(B: int, N: int, C: int, m: int, budget_bytes: int | None = None
             free, _total = torch.cuda.mem_get_info()
             cached = _lib._workspace.numel() if _lib._workspace is not None else 0
             budget_bytes = int(0.7 * (free + cached))
-    need = lambda k: int(lib.bark_mll_workspace_bytes(N, C, m, k))  # noqa: E731
     if need(B) <= budget_bytes:
         return int(B)
-    lo, hi = 1, int(B)  # largest chunk whose workspace fits (need() is monotone)
+    lo, hi = 1, int(B)
     while lo < hi:
         mid = (lo + hi + 1) // 2
         if need(mid) <= budget_bytes:
@@ -62,6 +62,12 @@ def choose_chunk(B: int, N: int, C: int, m: int, budget_bytes: int | None = None
         else:
             hi = mid - 1
     return lo
+
+
+def choose_chunk(B: int, N: int, C: int, m: int, budget_bytes: int | None = None) -> int:
+    """How many forests to factorise concurrently in the dense sweep: as many as fit the HBM budget."""
+    lib = _lib.lib()
+    return _fit_chunk(B, lambda k: int(lib.bark_mll_workspace_bytes(N, C, m, k)), budget_bytes)
 
 
 def _run(forest, noise, scale, X, y, feat_types, flags, cand=None, timing=None, chunk=None, shift=None,
@@ -207,24 +213,26 @@ def _run_leafspace(forest, noise, scale, X, y, feat_types, flags, chunk=None, ca
         mu = torch.empty((B, C), dtype=torch.float64, device=Xd.device)
         var = torch.empty((B, C), dtype=torch.float64, device=Xd.device)
     pf = PackedForest(nodes3, ft)
-    Bc = int(chunk or B)
+    R = int(pf.info.max_bits)
     out = torch.empty(B, dtype=torch.float64, device=Xd.device)
     info = torch.empty(B, dtype=torch.int32, device=Xd.device)
     K_inv = K_inv_y = None
     if want_inverse:
         if cand is not None:
             raise ValueError("candidates and want_inverse are separate calls")
-        if chunk is None:  # keep the (Bc, N, R) row-sum scratch modest next to the (B, N, N) result
-            Bc = max(1, min(B, (1 << 30) // max(1, 8 * N * int(pf.info.max_bits))))
-        ws = _lib.workspace(int(lib.bark_kernel_inverse_leafspace_workspace_bytes(N, int(pf.info.max_bits), pf.m, Bc)))
         K_inv = torch.empty((B, N, N), dtype=torch.float64, device=Xd.device)
         K_inv_y = torch.empty((B, N), dtype=torch.float64, device=Xd.device)
+        Bc = int(chunk) if chunk else _fit_chunk(
+            min(B, max(1, (1 << 30) // max(1, 8 * N * R))),  # keep the (Bc, N, R) row-sum scratch modest
+            lambda k: int(lib.bark_kernel_inverse_leafspace_workspace_bytes(N, R, pf.m, k)))
+        ws = _lib.workspace(int(lib.bark_kernel_inverse_leafspace_workspace_bytes(N, R, pf.m, Bc)))
         _lib.check(lib.bark_kernel_inverse_leafspace_hip(_lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(yd),
                                                          _lib.ptr(noise_d), _lib.ptr(scale_d), flags, _lib.ptr(out),
                                                          _lib.ptr(K_inv), _lib.ptr(K_inv_y), _lib.ptr(info), _lib.ptr(ws),
                                                          ws.numel(), Bc, _lib.stream_ptr()))
     else:
-        ws = _lib.workspace(int(lib.bark_mll_leafspace_workspace_bytes(N, int(pf.info.max_bits), pf.m, Bc, C)))
+        Bc = int(chunk) if chunk else _fit_chunk(B, lambda k: int(lib.bark_mll_leafspace_workspace_bytes(N, R, pf.m, k, C)))
+        ws = _lib.workspace(int(lib.bark_mll_leafspace_workspace_bytes(N, R, pf.m, Bc, C)))
         _lib.check(lib.bark_mll_leafspace_hip(_lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(yd),
                                               _lib.ptr(noise_d), _lib.ptr(scale_d), flags, _lib.ptr(cand_d), C,
                                               _lib.ptr(out), _lib.ptr(mu), _lib.ptr(var), _lib.ptr(info),
