@@ -353,6 +353,23 @@ __device__ __forceinline__ void mfma_nn(f64x4 &acc, const double *X, int ldx, co
 // (A): one wave eliminates the 16x16 diagonal sub-block `blk` (row stride SB) in registers and overwrites
 // it with W = U_kk^-1 (upper triangular, row-major).  Lane (g = l>>4, c = l&15) owns rows g, g+4, g+8,
 // g+12 of column c of [D | I].  Returns sum log(pivot) and the first bad pivot.
+// value of `v` in lane `src` (a wave-uniform, here compile-time, lane index): two v_readlane_b32 instead of the
+// LDS-crossbar ds_bpermute a general __shfl costs — this sits on the serial pivot chain of factor16
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// 1 / d for a positive, normal d: v_rcp_f64 plus two Newton steps (full double accuracy, not correctly rounded;
+// the IEEE division sequence is ~3x longer and also on the pivot chain)
+__device__ __forceinline__ double recip_pos(double d) {
+    double x = __builtin_amdgcn_rcp(d);
+    x = fma(fma(-d, x, 1.0), x, x);
+    x = fma(fma(-d, x, 1.0), x, x);
+    return x;
+}
+
 __device__ __forceinline__ void factor16(double *blk, int lane, int base_index, double &logsum, int &bad) {
     const int c = lane & 15, g = lane >> 4;
     double e[4], f[4];
@@ -364,12 +381,12 @@ __device__ __forceinline__ void factor16(double *blk, int lane, int base_index, 
 #pragma unroll
     for (int k = 0; k < SB; ++k) {
         const int kv = k >> 2, kl = (k & 3) * 16;  // row k lives in register kv of lane group k&3
-        double d = __shfl(e[kv], kl + k);
+        double d = readlane_f64(e[kv], kl + k);
         if (!(d > 0.0)) {  // not positive definite / NaN: flag once, continue finite
             if (!bad) bad = base_index + k + 1;
             d = 1.0;
         }
-        const double rd = 1.0 / d;
+        const double rd = recip_pos(d);
         const double lc = __shfl(e[kv], kl + c);  // D[k][c]
         const double rc = __shfl(f[kv], kl + c);  // I[k][c]
 #pragma unroll
