@@ -370,6 +370,42 @@ __device__ __forceinline__ double recip_pos(double d) {
     return x;
 }
 
+// lane K of every 16-lane row broadcast to that row (DPP row_newbcast:K): VALU speed, no LDS round trip
+template <int K>
+__device__ __forceinline__ double row_bcast_f64(double v) {
+    constexpr int ctrl = 0x150 + K;
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+// Elimination step K of factor16 on [D | I] (lane (g, c) holds rows g + 4v of column c in e[v] / f[v]).
+// Row K lives in register K >> 2 of lane group K & 3.  The multipliers D[K][r] / d for the lane's own rows are
+// read as D[r][K] (the trailing block stays symmetric): same 16-lane row, position K -> a DPP broadcast; only
+// the pivot row's entries D[K][c], I[K][c] cross lane groups (ds_bpermute), the pivot itself is a readlane.
+template <int K>
+__device__ __forceinline__ void pivot16(double (&e)[4], double (&f)[4], int c, int g, int base_index, int &bad) {
+    constexpr int kv = K >> 2, kl = (K & 3) * 16;
+    const double lc = __shfl(e[kv], kl + c);  // D[K][c]
+    const double rc = __shfl(f[kv], kl + c);  // I[K][c]
+    double d = readlane_f64(e[kv], kl + K);
+    if (!(d > 0.0)) {  // not positive definite / NaN: flag once, continue finite
+        if (!bad) bad = base_index + K + 1;
+        d = 1.0;
+    }
+    const double rd = recip_pos(d);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int r = g + 4 * v;
+        const double m = row_bcast_f64<K>(e[v]) * rd;  // D[r][K] / d
+        if (r > K) {
+            e[v] = fma(-m, lc, e[v]);
+            f[v] = fma(-m, rc, f[v]);
+        }
+    }
+    if constexpr (K + 1 < SB) pivot16<K + 1>(e, f, c, g, base_index, bad);
+}
+
 __device__ __forceinline__ void factor16(double *blk, int lane, int base_index, double &logsum, int &bad) {
     const int c = lane & 15, g = lane >> 4;
     double e[4], f[4];
@@ -378,27 +414,7 @@ __device__ __forceinline__ void factor16(double *blk, int lane, int base_index, 
         e[v] = blk[(g + 4 * v) * SB + c];
         f[v] = (g + 4 * v == c) ? 1.0 : 0.0;
     }
-#pragma unroll
-    for (int k = 0; k < SB; ++k) {
-        const int kv = k >> 2, kl = (k & 3) * 16;  // row k lives in register kv of lane group k&3
-        double d = readlane_f64(e[kv], kl + k);
-        if (!(d > 0.0)) {  // not positive definite / NaN: flag once, continue finite
-            if (!bad) bad = base_index + k + 1;
-            d = 1.0;
-        }
-        const double rd = recip_pos(d);
-        const double lc = __shfl(e[kv], kl + c);  // D[k][c]
-        const double rc = __shfl(f[kv], kl + c);  // I[k][c]
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int r = g + 4 * v;
-            const double m = __shfl(e[kv], kl + r) * rd;  // D[k][r] / d   (symmetric: == D[r][k] / d)
-            if (r > k) {
-                e[v] = fma(-m, lc, e[v]);
-                f[v] = fma(-m, rc, f[v]);
-            }
-        }
-    }
+    pivot16<0>(e, f, c, g, base_index, bad);
     // log|D| from the 16 frozen pivots, one per lane and in parallel (a serial log per elimination step costs
     // ~3 us per call on the one wave every other wave is waiting for): pivot r sits in register r >> 2 of lane
     // (r & 3, r).  Lanes 0..15 end up with the block's sum; the caller reads lane 0's.
