@@ -600,6 +600,48 @@ def test_not_positive_definite_raises(B):
         B.fit.batched_mll(forest, np.full(4, -0.5), None, X, y, ft, include_scale=False, include_2pi=True)
 
 
+def test_argument_validation_across_the_api(B):
+    """Bad shapes / unsupported options raise Python exceptions (SURVEY §8b error behaviour); nothing aborts."""
+    X, y, bounds, ft = B.syn.mixed_problem(90, seed=3)
+    F = B.syn.sample_prior_forests(3, 7, bounds, ft, seed=3)
+    noise, scale = np.full(3, 0.1), np.ones(3)
+    with pytest.raises(ValueError, match="noise"):
+        B.fit.batched_mll(F, noise[:2], scale, X, y, ft, include_scale=True, include_2pi=False)
+    with pytest.raises(ValueError, match="scale"):
+        B.fit.batched_mll(F, noise, scale[:1], X, y, ft, include_scale=True, include_2pi=False)
+    with pytest.raises(ValueError, match="rows"):
+        B.fit.batched_mll(F, noise, scale, X, y[:-1], ft, include_scale=True, include_2pi=False)
+    with pytest.raises(ValueError):
+        B.fit.batched_mll(F, noise, scale, X, y[:-1], ft, include_scale=True, include_2pi=False, method="leafspace")
+    model, cand = (F, noise, scale), X[:11]
+    with pytest.raises(ValueError, match="diagonal"):
+        B.tk.forest_predict(model, (X, y), cand, ft, diag=False, method="leafspace")
+    with pytest.raises(ValueError, match="unknown method"):
+        B.tk.forest_predict(model, (X, y), cand, ft, method="qr")
+    with pytest.raises(ValueError, match="features"):
+        B.tk.forest_predict(model, (X, y), cand[:, :4], ft)
+    many = B.syn.sample_prior_forests(1, 70, bounds, ft, seed=4)  # the leaf-space posterior gathers <= 64 trees
+    with pytest.raises(ValueError, match="64 trees"):
+        B.tk.forest_predict((many, noise[:1], scale[:1]), (X, y), cand, ft, method="leafspace")
+    mu, var = B.tk.forest_predict((many, noise[:1], scale[:1]), (X, y), cand, ft)  # the dense path has no such limit
+    mu0, var0 = B.orc.forest_predict((many, noise[:1], scale[:1]), (X, y), cand, ft)
+    assert np.allclose(mu, mu0, rtol=1e-9, atol=1e-9) and np.allclose(var, var0, rtol=1e-9, atol=1e-9)
+    # sampler state: row counts and the rank limit of a tree swap
+    state = B.fit.ChainState.from_forest(F[0], 0.1, 1.0, X, y, ft)
+    with pytest.raises(ValueError, match="rows"):
+        state.propose_tree(F[0][0], F[1][0], X[:50], ft, 1.0, 7)
+    with pytest.raises(ValueError, match="N rows"):
+        state.propose(np.ones((50, 2)), np.ones((90, 2)))
+    rng = np.random.default_rng(0)
+    bushy = B.syn.full_binary_forest(2, 12, 6, rng, node_limit=127)  # 64 leaves each: 128 columns in one swap
+    Xc = rng.uniform(size=(90, 12))
+    st2 = B.fit.ChainState.from_forest(bushy, 0.1, 1.0, Xc, y, np.full(12, 2))
+    with pytest.raises(ValueError, match="64"):
+        st2.propose_tree(bushy[0], bushy[1], Xc, np.full(12, 2), 1.0, 2)
+    with pytest.raises(RuntimeError):
+        st2.accept()
+
+
 def test_torch_tensors_stay_on_device(B):
     torch = B.torch
     g = load_golden("g3_prior_mixed_n64")
