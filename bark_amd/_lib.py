@@ -66,6 +66,10 @@ SIGNATURES = {
     "bark_lowrank_swap_eval_hip": (ci, [vp, i64, vp, i64, i64, vp, vp, vp, ctypes.c_size_t, vp]),
     "bark_lowrank_swap_apply_hip": (ci, [vp, i64, i64, vp, vp, vp]),
     "bark_tree_swap_workspace_bytes": (ctypes.c_size_t, [i64, i64]),
+    "bark_tree_swap_chains_workspace_bytes": (ctypes.c_size_t, [i64, i64, i64, vp]),
+    "bark_tree_swap_eval_chains_hip": (ci, [vp, i64, i64, vp, ctypes.POINTER(PackInfo), vp, i64, vp, vp, vp, vp, vp,
+                                            ctypes.c_size_t, vp]),
+    "bark_lowrank_swap_apply_chains_hip": (ci, [vp, i64, i64, i64, vp, vp, ctypes.c_size_t, vp]),
     "bark_tree_swap_eval_hip": (ci, [vp, i64, vp, ctypes.POINTER(PackInfo), vp, i64, i64, ctypes.c_double, vp, vp, vp,
                                      ctypes.c_size_t, vp]),
 }

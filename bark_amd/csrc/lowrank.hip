@@ -13,6 +13,8 @@
 //   4. rank_update_kernel   out = K_inv - M Y'   64x64 tiles, M/Y strips in LDS          (HBM read+write, 16 N^2 B)
 // K_inv is treated as a general (not necessarily symmetric) matrix exactly as the reference's formula does:
 // the right factor is U' K_inv, computed as its own pass when `symmetric == 0`.
+#include <vector>
+
 #include "common.h"
 
 namespace bark {
@@ -31,6 +33,20 @@ constexpr int LR_THREADS = 256;
 #endif
 
 typedef double lr_double2 __attribute__((ext_vector_type(2)));
+
+// Several independent chains in one launch: the chain index is the highest grid dimension a kernel does not use
+// otherwise; chain b's matrices sit `k` doubles apart and its workspace block (identical internal layout) `ws`
+// doubles apart.  Single-chain entry points launch with one chain, the strides are then irrelevant.
+constexpr int MAX_CHAINS = 64;
+struct Chain {
+    size_t k, ws;
+};
+struct ChainInts {
+    int v[MAX_CHAINS];
+};
+struct ChainDoubles {
+    double v[MAX_CHAINS];
+};
 
 // Y = K U for a skinny U (N x r), K row-major N x N, streamed once at HBM rate.
 // A workgroup owns 4*RW rows (RW per wave); a lane owns KL column pairs of every KC = 128*KL column chunk
@@ -179,8 +195,12 @@ inline int colsum_segment(int64_t N) { return 128 * (int)((N + 4095) / 4096); }
 
 template <int RT>
 __global__ __launch_bounds__(LR_THREADS) void colsum_kernel(const double *__restrict__ K, const double *__restrict__ U,
-                                                            int N, int r, int seg_rows, double *__restrict__ P) {
+                                                            int N, int r, int seg_rows, double *__restrict__ P,
+                                                            Chain ch) {
     extern __shared__ __attribute__((aligned(16))) double red[];  // [4][128][r]
+    K += blockIdx.z * ch.k;  // chain = blockIdx.z
+    U += blockIdx.z * ch.ws;
+    P += blockIdx.z * ch.ws;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = blockIdx.x * 128 + 2 * lane;
@@ -227,9 +247,13 @@ __global__ __launch_bounds__(LR_THREADS) void colsum_kernel(const double *__rest
 __global__ __launch_bounds__(LR_THREADS) void colsum_finish_kernel(const double *__restrict__ P, int segs,
                                                                    const double *__restrict__ U, int N, int r,
                                                                    double *__restrict__ Y, const double *__restrict__ y,
-                                                                   double *__restrict__ partial) {
+                                                                   double *__restrict__ partial, Chain ch) {
     extern __shared__ __attribute__((aligned(16))) double sh[];  // ys[ROWS][r] | ur[ROWS][r] | yv[ROWS]
     constexpr int ROWS = CS_FIN_ROWS;
+    P += blockIdx.y * ch.ws;  // chain = blockIdx.y; y is shared by the chains
+    U += blockIdx.y * ch.ws;
+    Y += blockIdx.y * ch.ws;
+    if (partial) partial += blockIdx.y * ch.ws;
     double *ys = sh, *ur = sh + ROWS * r, *yv = sh + 2 * ROWS * r;
     const int row0 = blockIdx.x * ROWS;
     const int rows = min(ROWS, N - row0);
@@ -266,7 +290,9 @@ __global__ __launch_bounds__(LR_THREADS) void colsum_finish_kernel(const double 
 
 // sums[e] = sum over blocks of partial[block][e], one wave per entry, fixed order
 __global__ __launch_bounds__(LR_THREADS) void reduce_shares_kernel(const double *__restrict__ partial, int nblocks,
-                                                                   int per, double *__restrict__ sums) {
+                                                                   int per, double *__restrict__ sums, Chain ch) {
+    partial += blockIdx.y * ch.ws;  // chain = blockIdx.y
+    sums += blockIdx.y * ch.ws;
     const int e = blockIdx.x * (LR_THREADS / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (e >= per) return;
     double g = 0.0;
@@ -316,14 +342,20 @@ __global__ __launch_bounds__(LR_THREADS) void skinny_t_kernel(const double *__re
 // columns carry -1: leaf vectors being removed), Gauss-Jordan with partial pivoting -> den^-1 (written to
 // `inv`, r x r) and log|det den|.  With `dquad`: v = sum of the v shares and dquad = v' den^-1 v (the change of
 // y'K^-1 y).  `logabsdet` / `dquad` may be null.
-__global__ __launch_bounds__(LR_THREADS) void small_kernel(const double *__restrict__ sums, int r, int r_neg,
+__global__ __launch_bounds__(LR_THREADS) void small_kernel(const double *__restrict__ sums, int r, ChainInts r_negs,
                                                            double *__restrict__ inv,
                                                            double *__restrict__ logabsdet, int *__restrict__ singular,
-                                                           double *__restrict__ dquad) {
+                                                           double *__restrict__ dquad, Chain ch, int out_stride) {
     __shared__ double aug[LR_MAX][2 * LR_MAX + 1];  // [den | I]
     __shared__ double vsh[LR_MAX];
     __shared__ int piv_row;
     const int tid = threadIdx.x;
+    const int r_neg = r_negs.v[blockIdx.x];  // chain = blockIdx.x; scalar outputs are out_stride doubles apart
+    sums += blockIdx.x * ch.ws;
+    if (inv) inv += blockIdx.x * ch.ws;
+    if (singular) singular = reinterpret_cast<int *>(reinterpret_cast<double *>(singular) + blockIdx.x * ch.ws);
+    if (logabsdet) logabsdet += (size_t)blockIdx.x * out_stride;
+    if (dquad) dquad += (size_t)blockIdx.x * out_stride;
     for (int e = tid; e < r * r + r; e += LR_THREADS) {
         const double g = sums[e];
         if (e < r * r) {
@@ -385,8 +417,12 @@ __global__ __launch_bounds__(LR_THREADS) void small_kernel(const double *__restr
 // M = Y den^-1 (N x r): one thread per entry, den^-1 in LDS.
 __global__ __launch_bounds__(LR_THREADS) void left_factor_kernel(const double *__restrict__ Y,
                                                                  const double *__restrict__ inv, int N, int r,
-                                                                 double *__restrict__ M) {
+                                                                 double *__restrict__ M, Chain ch, ChainInts accept) {
     __shared__ double is[LR_MAX * LR_MAX];
+    if (!accept.v[blockIdx.y]) return;  // chain = blockIdx.y (uniform per workgroup)
+    Y += blockIdx.y * ch.ws;
+    inv += blockIdx.y * ch.ws;
+    M += blockIdx.y * ch.ws;
     for (int e = threadIdx.x; e < r * r; e += LR_THREADS) is[e] = inv[e];
     __syncthreads();
     const size_t e = (size_t)blockIdx.x * LR_THREADS + threadIdx.x;
@@ -401,8 +437,13 @@ __global__ __launch_bounds__(LR_THREADS) void left_factor_kernel(const double *_
 __global__ __launch_bounds__(LR_THREADS) void rank_update_kernel(const double *__restrict__ K,
                                                                  const double *__restrict__ M,
                                                                  const double *__restrict__ R, int N, int r,
-                                                                 double *__restrict__ out) {
+                                                                 double *__restrict__ out, Chain ch, ChainInts accept) {
     extern __shared__ __attribute__((aligned(16))) double strips[];  // Ms[64][r] | Rs[64][r]
+    if (!accept.v[blockIdx.z]) return;  // chain = blockIdx.z (uniform per workgroup)
+    K += blockIdx.z * ch.k;
+    out += blockIdx.z * ch.k;
+    M += blockIdx.z * ch.ws;
+    R += blockIdx.z * ch.ws;
     double *Ms = strips, *Rs = strips + 64 * r;
     const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
     for (int e = threadIdx.x; e < 64 * r; e += LR_THREADS) {
@@ -424,8 +465,12 @@ __global__ __launch_bounds__(LR_THREADS) void rank_update_kernel(const double *_
 }
 
 // U[i][c] = s if bit c of point i's one-hot leaf code is set else 0  (codes: [words][npad] planes)
-__global__ __launch_bounds__(LR_THREADS) void expand_onehot_kernel(const uint32_t *__restrict__ codes, int npad, int N,
-                                                                   int r, double s, double *__restrict__ U) {
+__global__ __launch_bounds__(LR_THREADS) void expand_onehot_kernel(const uint32_t *__restrict__ codes, int words, int npad,
+                                                                   int N, int r, ChainDoubles scales,
+                                                                   double *__restrict__ U, Chain ch) {
+    const double s = scales.v[blockIdx.y];  // chain = blockIdx.y; codes are (chains, words, npad) contiguous
+    codes += (size_t)blockIdx.y * words * npad;
+    U += blockIdx.y * ch.ws;
     const size_t e = (size_t)blockIdx.x * LR_THREADS + threadIdx.x;
     if (e >= (size_t)N * r) return;
     const int i = (int)(e / r), c = (int)(e - (size_t)i * r);
@@ -475,27 +520,45 @@ int launch_skinny(hipStream_t stream, const double *K, const double *U, int N, i
 bool colsum_usable(int64_t N, int64_t r) { return N % 2 == 0 && r <= 16; }
 
 int launch_colsum(hipStream_t stream, const double *K, const double *U, int N, int r, double *P, double *out,
-                  const double *y, double *partial) {
+                  const double *y, double *partial, int nc = 1, Chain ch = Chain{0, 0}) {
     const int seg_rows = colsum_segment(N), segs = (N + seg_rows - 1) / seg_rows;
-    const dim3 grid((unsigned)((N + 127) / 128), (unsigned)segs);
+    const dim3 grid((unsigned)((N + 127) / 128), (unsigned)segs, (unsigned)nc);
     const size_t lds = (size_t)4 * 128 * r * sizeof(double);  // 64 KiB at r = 16
     if (r <= 8)
-        hipLaunchKernelGGL((colsum_kernel<8>), grid, dim3(LR_THREADS), lds, stream, K, U, N, r, seg_rows, P);
+        hipLaunchKernelGGL((colsum_kernel<8>), grid, dim3(LR_THREADS), lds, stream, K, U, N, r, seg_rows, P, ch);
     else
-        hipLaunchKernelGGL((colsum_kernel<16>), grid, dim3(LR_THREADS), lds, stream, K, U, N, r, seg_rows, P);
+        hipLaunchKernelGGL((colsum_kernel<16>), grid, dim3(LR_THREADS), lds, stream, K, U, N, r, seg_rows, P, ch);
     const int nblocks = (N + CS_FIN_ROWS - 1) / CS_FIN_ROWS;
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)nblocks), dim3(LR_THREADS),
-                       (size_t)(2 * CS_FIN_ROWS * r + CS_FIN_ROWS) * sizeof(double), stream, P, segs, U, N, r, out, y, partial);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)nblocks, (unsigned)nc), dim3(LR_THREADS),
+                       (size_t)(2 * CS_FIN_ROWS * r + CS_FIN_ROWS) * sizeof(double), stream, P, segs, U, N, r, out, y, partial, ch);
     return nblocks;
 }
 
 // shares -> sums -> den^-1, log|det|, dquad
-void launch_small(hipStream_t stream, const double *partial, int nblocks, int r, int r_neg, double *sums, double *inv,
-                  double *logabsdet, int *flag, double *dquad) {
+void launch_small(hipStream_t stream, const double *partial, int nblocks, int r, const ChainInts &r_neg, double *sums,
+                  double *inv, double *logabsdet, int *flag, double *dquad, int nc = 1, Chain ch = Chain{0, 0},
+                  int out_stride = 0) {
     const int per = r * r + r;
-    hipLaunchKernelGGL(reduce_shares_kernel, dim3((unsigned)((per + 3) / 4)), dim3(LR_THREADS), 0, stream, partial,
-                       nblocks, per, sums);
-    hipLaunchKernelGGL(small_kernel, dim3(1), dim3(LR_THREADS), 0, stream, sums, r, r_neg, inv, logabsdet, flag, dquad);
+    hipLaunchKernelGGL(reduce_shares_kernel, dim3((unsigned)((per + 3) / 4), (unsigned)nc), dim3(LR_THREADS), 0, stream,
+                       partial, nblocks, per, sums, ch);
+    hipLaunchKernelGGL(small_kernel, dim3((unsigned)nc), dim3(LR_THREADS), 0, stream, sums, r, r_neg, inv, logabsdet, flag,
+                       dquad, ch, out_stride);
+}
+
+ChainInts one_int(int v) {
+    ChainInts c = {};
+    c.v[0] = v;
+    return c;
+}
+
+// M = Y den^-1, then out = K - M R'  for the chains whose accept entry is set
+void launch_rewrite(hipStream_t stream, const double *K, int N, int r, const double *Y, const double *inv, double *M,
+                    const double *R, double *out, const ChainInts &accept, int nc = 1, Chain ch = Chain{0, 0}) {
+    hipLaunchKernelGGL(left_factor_kernel, dim3((unsigned)(((size_t)N * r + LR_THREADS - 1) / LR_THREADS), (unsigned)nc),
+                       dim3(LR_THREADS), 0, stream, Y, inv, N, r, M, ch, accept);
+    const unsigned tiles = (unsigned)((N + 63) / 64);
+    hipLaunchKernelGGL(rank_update_kernel, dim3(tiles, tiles, (unsigned)nc), dim3(LR_THREADS),
+                       (size_t)2 * 64 * r * sizeof(double), stream, K, M, R, N, r, out, ch, accept);
 }
 
 void launch_skinny_t(hipStream_t stream, const double *K, const double *U, int N, int r, double *out) {
@@ -576,16 +639,11 @@ int bark_lowrank_update_hip(const double *K_inv, int64_t N, const double *U, int
         Rp = w.R;
     }
     BARK_HIP_CHECK(hipMemsetAsync(w.flag, 0, sizeof(int), stream));
-    launch_small(stream, w.partial, nblocks, (int)r, r_neg, w.sums, K_out ? w.inv : nullptr, logabsdet_out, w.flag,
+    launch_small(stream, w.partial, nblocks, (int)r, one_int(r_neg), w.sums, K_out ? w.inv : nullptr, logabsdet_out, w.flag,
                  nullptr);
     BARK_LAUNCH_CHECK();
     if (K_out) {
-        hipLaunchKernelGGL(left_factor_kernel, dim3((unsigned)((N * r + LR_THREADS - 1) / LR_THREADS)), dim3(LR_THREADS), 0,
-                           stream, w.Y, w.inv, (int)N, (int)r, w.M);
-        BARK_LAUNCH_CHECK();
-        const dim3 g3((unsigned)((N + 63) / 64), (unsigned)((N + 63) / 64));
-        hipLaunchKernelGGL(rank_update_kernel, g3, dim3(LR_THREADS), (size_t)2 * 64 * r * sizeof(double), stream, K_inv,
-                           w.M, Rp, (int)N, (int)r, K_out);
+        launch_rewrite(stream, K_inv, (int)N, (int)r, w.Y, w.inv, w.M, Rp, K_out, one_int(1));
         BARK_LAUNCH_CHECK();
     }
     return BARK_OK;
@@ -615,7 +673,7 @@ int bark_lowrank_swap_eval_hip(const double *K_inv, int64_t N, const double *U, 
                                             : launch_skinny(stream, K_inv, U, (int)N, (int)r, w.Y, y, w.partial);
     BARK_LAUNCH_CHECK();
     BARK_HIP_CHECK(hipMemsetAsync(w.flag, 0, sizeof(int), stream));
-    launch_small(stream, w.partial, nblocks, (int)r, (int)r_old, w.sums, w.inv, scalars_out + 1, w.flag, scalars_out);
+    launch_small(stream, w.partial, nblocks, (int)r, one_int((int)r_old), w.sums, w.inv, scalars_out + 1, w.flag, scalars_out);
     BARK_LAUNCH_CHECK();
     return BARK_OK;
 }
@@ -627,12 +685,7 @@ int bark_lowrank_swap_apply_hip(const double *K_inv, int64_t N, int64_t r, void 
         return fail(BARK_ERR_ARG, "bark_lowrank_swap_apply_hip: bad argument");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const LowRankWs w = lowrank_ws(workspace, N, r);
-    hipLaunchKernelGGL(left_factor_kernel, dim3((unsigned)((N * r + LR_THREADS - 1) / LR_THREADS)), dim3(LR_THREADS), 0,
-                       stream, w.Y, w.inv, (int)N, (int)r, w.M);
-    BARK_LAUNCH_CHECK();
-    const dim3 g3((unsigned)((N + 63) / 64), (unsigned)((N + 63) / 64));
-    hipLaunchKernelGGL(rank_update_kernel, g3, dim3(LR_THREADS), (size_t)2 * 64 * r * sizeof(double), stream, K_inv, w.M,
-                       w.Y, (int)N, (int)r, K_out);
+    launch_rewrite(stream, K_inv, (int)N, (int)r, w.Y, w.inv, w.M, w.Y, K_out, one_int(1));
     BARK_LAUNCH_CHECK();
     return BARK_OK;
 }
@@ -672,10 +725,146 @@ int bark_tree_swap_eval_hip(const double *K_inv, int64_t N, const void *packed, 
     const int words = (int)((r + 31) / 32);
     int rc = walk_one_hot(packed, info, X, N, d, words, codes, stream);
     if (rc) return rc;
+    ChainDoubles scales = {};
+    scales.v[0] = s;
     hipLaunchKernelGGL(expand_onehot_kernel, dim3((unsigned)((N * r + LR_THREADS - 1) / LR_THREADS)), dim3(LR_THREADS), 0,
-                       stream, codes, (int)bark_leaf_npad(N), (int)N, (int)r, s, U);
+                       stream, codes, words, (int)bark_leaf_npad(N), (int)N, (int)r, scales, U, Chain{0, 0});
     BARK_LAUNCH_CHECK();
     return bark_lowrank_swap_eval_hip(K_inv, N, U, r_old, r - r_old, y, scalars_out, workspace, base, stream_);
+}
+
+// ---- several chains in one call ---------------------------------------------------------------------
+// The chains of the sampler are independent (bark_sampler.py:147 loops over them); one proposal is a short,
+// latency-bound launch sequence around a single streaming pass.  Each chain's sequence is enqueued on its own
+// stream forked from the caller's, so the sequences overlap on the GPU and the host pays one call and one
+// synchronisation for all of them.  K_inv: (nc, N, N); packed/info: nc forests of TWO trees [old, new]
+// (bark_forest_pack, B = nc, m = 2); r_old, s: host arrays (nc); scalars_out: device (nc, 2); workspace of
+// bark_tree_swap_chains_workspace_bytes(N, info->max_bits, nc) bytes.  With N even and <= 16 leaves per pair the
+// chain index is a grid dimension of every kernel (one launch sequence for all chains); otherwise one
+// single-chain sequence per chain, each on its own stream.
+namespace {
+struct ChainStreams {
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> done;
+    hipEvent_t fork = nullptr;
+};
+
+int chain_streams(ChainStreams **out, size_t n) {
+    static thread_local ChainStreams per_device[32];
+    int dev = 0;
+    BARK_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 32) return fail(BARK_ERR_ARG, "device index %d out of range", dev);
+    ChainStreams &c = per_device[dev];
+    if (!c.fork) BARK_HIP_CHECK(hipEventCreateWithFlags(&c.fork, hipEventDisableTiming));
+    while (c.streams.size() < n) {
+        hipStream_t st;
+        hipEvent_t ev;
+        BARK_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        BARK_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        c.streams.push_back(st);
+        c.done.push_back(ev);
+    }
+    *out = &c;
+    return BARK_OK;
+}
+}  // namespace
+
+size_t bark_tree_swap_chains_workspace_bytes(int64_t N, int64_t r, int64_t nc, size_t *chain_stride_bytes) {
+    if (N < 1 || r < 1 || r > LR_MAX || nc < 1 || nc > MAX_CHAINS) return 0;
+    const size_t stride = (size_t)round_up((int64_t)bark_tree_swap_workspace_bytes(N, r), 256);
+    if (chain_stride_bytes) *chain_stride_bytes = stride;
+    // nc per-chain blocks, then the one-hot codes of all chains, contiguous (one leaf walk for all of them)
+    return stride * (size_t)nc + (size_t)nc * (size_t)((r + 31) / 32) * (size_t)bark_leaf_npad(N) * sizeof(uint32_t);
+}
+
+int bark_tree_swap_eval_chains_hip(const double *K_inv, int64_t N, int64_t nc, const void *packed,
+                                   const bark_pack_info *info, const double *X, int64_t d, const int64_t *r_old,
+                                   const double *s, const double *y, double *scalars_out, void *workspace,
+                                   size_t workspace_bytes, void *stream_) {
+    error_buffer()[0] = 0;
+    if (!K_inv || !packed || !info || !X || !r_old || !s || !y || !scalars_out || !workspace || N < 1 || d < 1 || nc < 1 ||
+        nc > MAX_CHAINS || N > (1 << 24))
+        return fail(BARK_ERR_ARG, "bark_tree_swap_eval_chains_hip: bad argument (1 <= chains <= %d)", MAX_CHAINS);
+    if (info->B != nc || info->m != 2) return fail(BARK_ERR_ARG, "pack one [old tree, new tree] pair per chain (B = chains, m = 2)");
+    const int64_t r = info->max_bits;
+    if (r < 2 || r > LR_MAX) return fail(BARK_ERR_ARG, "tree swap supports 2..%d leaves in total (got %lld)", LR_MAX, (long long)r);
+    for (int64_t b = 0; b < nc; ++b)
+        if (r_old[b] < 1 || r_old[b] >= r) return fail(BARK_ERR_ARG, "chain %lld: r_old = %lld is not inside (0, %lld)", (long long)b, (long long)r_old[b], (long long)r);
+    size_t stride = 0;
+    if (workspace_bytes < bark_tree_swap_chains_workspace_bytes(N, r, nc, &stride))
+        return fail(BARK_ERR_WORKSPACE, "tree-swap workspace too small for %lld chains", (long long)nc);
+    hipStream_t caller = static_cast<hipStream_t>(stream_);
+    char *ws = static_cast<char *>(workspace);
+    if (colsum_usable(N, r)) {
+        // one launch sequence for all chains: the chain index is a grid dimension of every kernel
+        const Chain ch{(size_t)N * (size_t)N, stride / sizeof(double)};
+        const LowRankWs w = lowrank_ws(ws, N, r);
+        const size_t base = (size_t)round_up((int64_t)w.bytes, 256);
+        double *U = reinterpret_cast<double *>(ws + base);
+        uint32_t *codes = reinterpret_cast<uint32_t *>(ws + stride * (size_t)nc);
+        const int words = (int)((r + 31) / 32);
+        int rc = walk_one_hot(packed, info, X, N, d, words, codes, caller);
+        if (rc) return rc;
+        ChainDoubles scales = {};
+        ChainInts r_negs = {};
+        for (int64_t b = 0; b < nc; ++b) {
+            scales.v[b] = s[b];
+            r_negs.v[b] = (int)r_old[b];
+        }
+        hipLaunchKernelGGL(expand_onehot_kernel, dim3((unsigned)((N * r + LR_THREADS - 1) / LR_THREADS), (unsigned)nc),
+                           dim3(LR_THREADS), 0, caller, codes, words, (int)bark_leaf_npad(N), (int)N, (int)r, scales, U, ch);
+        BARK_LAUNCH_CHECK();
+        const int nblocks = launch_colsum(caller, K_inv, U, (int)N, (int)r, w.P, w.Y, y, w.partial, (int)nc, ch);
+        BARK_LAUNCH_CHECK();
+        BARK_HIP_CHECK(hipMemset2DAsync(w.flag, stride, 0, sizeof(int), (size_t)nc, caller));
+        launch_small(caller, w.partial, nblocks, (int)r, r_negs, w.sums, w.inv, scalars_out + 1, w.flag, scalars_out, (int)nc,
+                     ch, 2);
+        BARK_LAUNCH_CHECK();
+        return BARK_OK;
+    }
+    // general shapes (odd N, more than 16 leaves): one single-chain sequence per chain, each on its own stream
+    ChainStreams *cs = nullptr;
+    int rc = chain_streams(&cs, (size_t)nc);
+    if (rc) return rc;
+    BARK_HIP_CHECK(hipEventRecord(cs->fork, caller));
+    bark_pack_info one = *info;
+    one.B = 1;
+    for (int64_t b = 0; b < nc; ++b) {
+        hipStream_t st = cs->streams[(size_t)b];
+        BARK_HIP_CHECK(hipStreamWaitEvent(st, cs->fork, 0));
+        rc = bark_tree_swap_eval_hip(K_inv + (size_t)b * N * N, N,
+                                     static_cast<const char *>(packed) + (size_t)b * 2 * info->stride * 16, &one, X, d,
+                                     r_old[b], s[b], y, scalars_out + 2 * b, ws + (size_t)b * stride, stride, st);
+        // the join is recorded even after a failure so that the caller's stream never waits on nothing
+        BARK_HIP_CHECK(hipEventRecord(cs->done[(size_t)b], st));
+        BARK_HIP_CHECK(hipStreamWaitEvent(caller, cs->done[(size_t)b], 0));
+        if (rc) return rc;
+    }
+    return BARK_OK;
+}
+
+// accept[b] != 0: K_inv[b] <- K_inv[b] - Y (C+G)^-1 Y' from chain b's workspace block (host array, nc entries)
+int bark_lowrank_swap_apply_chains_hip(double *K_inv, int64_t N, int64_t nc, int64_t r, const int32_t *accept,
+                                       void *workspace, size_t workspace_bytes, void *stream_) {
+    error_buffer()[0] = 0;
+    if (!K_inv || !accept || !workspace || N < 1 || nc < 1 || nc > MAX_CHAINS || r < 1 || r > LR_MAX)
+        return fail(BARK_ERR_ARG, "bark_lowrank_swap_apply_chains_hip: bad argument");
+    size_t stride = 0;
+    if (workspace_bytes < bark_tree_swap_chains_workspace_bytes(N, r, nc, &stride))
+        return fail(BARK_ERR_WORKSPACE, "tree-swap workspace too small for %lld chains", (long long)nc);
+    hipStream_t caller = static_cast<hipStream_t>(stream_);
+    const Chain ch{(size_t)N * (size_t)N, stride / sizeof(double)};
+    const LowRankWs w = lowrank_ws(workspace, N, r);
+    ChainInts acc = {};
+    bool any = false;
+    for (int64_t b = 0; b < nc; ++b) {
+        acc.v[b] = accept[b] != 0;
+        any = any || acc.v[b];
+    }
+    if (!any) return BARK_OK;
+    launch_rewrite(caller, K_inv, (int)N, (int)r, w.Y, w.inv, w.M, w.Y, K_inv, acc, (int)nc, ch);
+    BARK_LAUNCH_CHECK();
+    return BARK_OK;
 }
 
 }  // extern "C"

@@ -154,3 +154,98 @@ class ChainState:
         dquad, dlogdet = (float(v) for v in scalars.cpu().numpy())
         self._pending = (ws, r, self.quad - dquad, self.logdet + dlogdet)
         return 0.5 * (-(self.quad - dquad) - (self.logdet + dlogdet))
+
+
+class ChainBatch:
+    """`ChainState` for several independent chains of the sampler (bark_sampler.py:147): K_inv (nc, N, N) resident,
+    the per-tree proposals of all chains evaluated by ONE library call — the chain index is a grid dimension of
+    every kernel, so the call costs one launch sequence — and one host synchronisation.  The chains share X and y (as in the reference)."""
+
+    def __init__(self, K_inv, K_logdet, y):
+        import torch
+
+        self.K_inv = _dev64(K_inv)
+        if self.K_inv.ndim != 3 or self.K_inv.shape[1] != self.K_inv.shape[2]:
+            raise ValueError(f"K_inv must be (chains, N, N), got {tuple(self.K_inv.shape)}")
+        self.nc, self.N = int(self.K_inv.shape[0]), int(self.K_inv.shape[1])
+        if not 1 <= self.nc <= 64:
+            raise ValueError("1 to 64 chains")
+        self.y = _dev64(y).reshape(-1).contiguous()
+        if self.y.shape[0] != self.N:
+            raise ValueError(f"y has {self.y.shape[0]} rows, K_inv is {self.N} x {self.N}")
+        self.logdet = np.asarray(K_logdet, dtype=np.float64).reshape(-1).copy()
+        if self.logdet.shape[0] != self.nc:
+            raise ValueError("one log-determinant per chain")
+        self.quad = (torch.einsum("i,bij,j->b", self.y, self.K_inv, self.y)).cpu().numpy()
+        self._scalars = torch.empty((self.nc, 2), dtype=torch.float64, device=self.K_inv.device)
+        self._ws = {}
+        self._pending = None
+        self._X_seen = None
+
+    @classmethod
+    def from_forests(cls, forests, noise, scale, X, y, feat_types, method: str = "dense"):
+        """Initial state of every chain (bark_sampler.py:153-162); forests (chains, m, node_limit)."""
+        nodes = np.asarray(forests)
+        K_inv, _, logdet = batched_kernel_inverse(nodes, noise, scale, X, y, feat_types, no_null=False,
+                                                  return_device=True, method=method)
+        return cls(K_inv, logdet.cpu().numpy(), y)
+
+    @property
+    def mll(self) -> np.ndarray:
+        """quick_inverse.py:37-38 for every chain."""
+        return 0.5 * (-self.quad - self.logdet)
+
+    def propose_trees(self, old_trees, new_trees, X, feat_types, scale, m: int) -> np.ndarray:
+        """bark_sampler.py:233-256 for one tree per chain: old_trees / new_trees (chains, node_limit) records,
+        scale (chains,) -> the (chains,) MLL values the chains would have.  `accept(mask)` commits."""
+        import torch
+
+        lib = _lib.lib()
+        ft = _feat_types(feat_types)
+        if self._X_seen is None or self._X_seen[0] is not X:
+            Xd, _ = _points(X, ft.shape[0])
+            _check_categorical(Xd, ft)
+            self._X_seen = (X, Xd)
+        Xd = self._X_seen[1]
+        if Xd.shape[0] != self.N:
+            raise ValueError(f"X has {Xd.shape[0]} rows, the chains have {self.N} points")
+        old, new = _as_nodes(old_trees, 2), _as_nodes(new_trees, 2)
+        if old.shape != new.shape or old.ndim != 2 or old.shape[0] != self.nc:
+            raise ValueError(f"trees must be (chains, node_limit) records, got {old.shape} and {new.shape}")
+        scale = np.broadcast_to(np.asarray(scale, dtype=np.float64).reshape(-1), (self.nc,))
+        r_old = np.empty(self.nc, dtype=np.int64)
+        info_one = _lib.PackInfo()
+        for b in range(self.nc):  # leaves of each old tree alone = the split between removed and added columns
+            _lib.check(lib.bark_forest_pack_info(_lib.ptr(np.ascontiguousarray(old[b])), 1, 1, old.shape[1], _lib.ptr(ft),
+                                                 ft.shape[0], ctypes.byref(info_one)))
+            r_old[b] = info_one.max_bits
+        pf = PackedForest(np.stack([old, new], axis=1), ft)  # (chains, 2, L): one [old, new] pair per chain
+        r = int(pf.info.max_bits)
+        if r > 64:
+            raise ValueError(f"tree swap supports at most 64 leaves in total (got {r})")
+        ws = self._ws.get(r)
+        if ws is None:
+            nbytes = int(lib.bark_tree_swap_chains_workspace_bytes(self.N, r, self.nc, None))
+            ws = self._ws[r] = torch.empty(nbytes, dtype=torch.uint8, device=self.K_inv.device)
+        s_sqrtm = np.ascontiguousarray(np.sqrt(scale / m))
+        _lib.check(lib.bark_tree_swap_eval_chains_hip(_lib.ptr(self.K_inv), self.N, self.nc, _lib.ptr(pf.packed), pf.info_ref,
+                                                      _lib.ptr(Xd), Xd.shape[1], _lib.ptr(r_old), _lib.ptr(s_sqrtm),
+                                                      _lib.ptr(self.y), _lib.ptr(self._scalars), _lib.ptr(ws), ws.numel(),
+                                                      _lib.stream_ptr()))
+        sc = self._scalars.cpu().numpy()
+        quad, logdet = self.quad - sc[:, 0], self.logdet + sc[:, 1]
+        self._pending = (ws, r, quad, logdet)
+        return 0.5 * (-quad - logdet)
+
+    def accept(self, mask) -> None:
+        """Commit the pending proposals of the chains where `mask` is true (bark_sampler.py:259-264)."""
+        if self._pending is None:
+            raise RuntimeError("accept() without a pending propose_trees()")
+        ws, r, quad, logdet = self._pending
+        mask = np.ascontiguousarray(np.broadcast_to(np.asarray(mask).reshape(-1), (self.nc,)), dtype=np.int32)
+        _lib.check(_lib.lib().bark_lowrank_swap_apply_chains_hip(_lib.ptr(self.K_inv), self.N, self.nc, r, _lib.ptr(mask),
+                                                                 _lib.ptr(ws), ws.numel(), _lib.stream_ptr()))
+        keep = mask != 0
+        self.quad = np.where(keep, quad, self.quad)
+        self.logdet = np.where(keep, logdet, self.logdet)
+        self._pending = None

@@ -236,6 +236,21 @@ int bark_tree_swap_eval_hip(const double *K_inv, int64_t N, const void *packed, 
                             const double *X, int64_t d, int64_t r_old, double s, const double *y, double *scalars_out,
                             void *workspace, size_t workspace_bytes, void *stream);
 
+/* The proposals of several independent chains (bark_sampler.py:147) in one call.  K_inv: (nc, N, N) device;
+ * packed/info: nc forests of two trees [old, new] (B = nc, m = 2); r_old, s: HOST arrays (nc); scalars_out: device
+ * (nc, 2) as in bark_lowrank_swap_eval_hip; workspace: bark_tree_swap_chains_workspace_bytes(N, info->max_bits, nc)
+ * bytes (nc per-chain blocks of *chain_stride_bytes, then the leaf codes of all chains).  1 <= nc <= 64.
+ * With N even and at most 16 leaves per pair every kernel takes the chain index from its grid (one launch sequence
+ * for all chains); otherwise each chain's single-chain sequence runs on its own stream forked from `stream`.
+ * ..._apply_chains: K_inv[b] is rewritten in place for every b with accept[b] != 0 (HOST int32 array). */
+size_t bark_tree_swap_chains_workspace_bytes(int64_t N, int64_t r, int64_t nc, size_t *chain_stride_bytes);
+int bark_tree_swap_eval_chains_hip(const double *K_inv, int64_t N, int64_t nc, const void *packed,
+                                   const bark_pack_info *info, const double *X, int64_t d, const int64_t *r_old,
+                                   const double *s, const double *y, double *scalars_out, void *workspace,
+                                   size_t workspace_bytes, void *stream);
+int bark_lowrank_swap_apply_chains_hip(double *K_inv, int64_t N, int64_t nc, int64_t r, const int32_t *accept,
+                                       void *workspace, size_t workspace_bytes, void *stream);
+
 /* quick_inverse.py:37-38  mll(K_inv, K_logdet, y) = 0.5 * (-y' K_inv y - K_logdet), on device. */
 int bark_quadform_hip(const double *K_inv, const double *y, int64_t N, double *out, void *stream);
 

@@ -496,6 +496,42 @@ def test_fused_tree_swap_matches_reference_chain(B):
     assert np.isclose(state.propose_tree(forest[7], fresh[7], X, ft, new_scale, m), want, rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("N", [300, 301])
+def test_chain_batch_matches_single_chains(B, N):
+    """Several chains in one call give exactly the single-chain results, chain by chain, including a partial
+    accept.  N = 300: the chain index is a grid dimension of every kernel; N = 301 (odd): per-chain sequences on
+    their own streams."""
+    X, y, bounds, ft = B.syn.mixed_problem(N, seed=14)
+    m, nc = 12, 3
+    forests = B.syn.sample_prior_forests(nc, m, bounds, ft, seed=14)
+    fresh = B.syn.sample_prior_forests(nc, m, bounds, ft, seed=15, alpha=0.95, beta=1.0)
+    noise, scale = np.array([0.1, 0.05, 0.2]), np.array([1.0, 1.4, 0.7])
+    batch = B.fit.ChainBatch.from_forests(forests, noise, scale, X, y, ft)
+    singles = [B.fit.ChainState.from_forest(forests[b], noise[b], scale[b], X, y, ft) for b in range(nc)]
+    assert np.allclose(batch.mll, [s.mll for s in singles], rtol=1e-12)
+    for t_idx in range(4):
+        got = batch.propose_trees(forests[:, t_idx], fresh[:, t_idx], X, ft, scale, m)
+        want = [singles[b].propose_tree(forests[b, t_idx], fresh[b, t_idx], X, ft, scale[b], m) for b in range(nc)]
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-12), (t_idx, got, want)
+        mask = np.array([True, t_idx % 2 == 0, False])
+        batch.accept(mask)
+        for b in range(nc):
+            if mask[b]:
+                singles[b].accept()
+                forests[b, t_idx] = fresh[b, t_idx]
+        assert np.allclose(batch.mll, [s.mll for s in singles], rtol=1e-12)
+    for b in range(nc):
+        assert np.array_equal(batch.K_inv[b].cpu().numpy(), singles[b].K_inv.cpu().numpy())
+    # and the states are the exact inverses of the chains' current kernels
+    for b in range(nc):
+        K = scale[b] * B.orc.forest_gram_matrix(forests[b], X, X, ft) + (1e-6 + noise[b]) * np.eye(N)
+        assert np.allclose(batch.K_inv[b].cpu().numpy(), np.linalg.inv(K), rtol=1e-7, atol=1e-8)
+    with pytest.raises(RuntimeError):
+        batch.accept(True)
+    with pytest.raises(ValueError):
+        batch.propose_trees(forests[:2, 0], fresh[:2, 0], X, ft, scale, m)
+
+
 def test_woodbury_large_against_oracle(B):
     """N = 1500, r = 7 / 33 / 64: one-hot style and dense U, symmetric SPD K_inv."""
     rng = np.random.default_rng(3)

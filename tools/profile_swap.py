@@ -33,6 +33,11 @@ for _ in range(reps):
     state.propose_tree(forest[0], fresh[0], Xd, ft, scale, m)
 torch.cuda.synchronize()
 print(f"propose_tree       : {(time.perf_counter() - t) / reps * 1e3:.3f} ms")
+state.propose(cur, new)  # warm-up of the accept path (first launch of its kernels)
+state.accept()
+state.propose(new, cur)
+state.accept()
+torch.cuda.synchronize()
 t = time.perf_counter()
 for _ in range(reps):
     state.propose(cur, new)
@@ -41,3 +46,17 @@ for _ in range(reps):
     state.accept()
 torch.cuda.synchronize()
 print(f"propose + accept   : {(time.perf_counter() - t) / (2 * reps) * 1e3:.3f} ms")
+
+# several chains in one call (each chain's sequence on its own stream)
+nc = 4
+forests = syn.sample_prior_forests(nc, m, bounds, ft, seed=11)
+others = syn.sample_prior_forests(nc, m, bounds, ft, seed=12)
+batch = fit.ChainBatch.from_forests(forests, np.full(nc, noise), np.full(nc, scale), Xd, y, ft)
+batch.propose_trees(forests[:, 0], others[:, 0], Xd, ft, np.full(nc, scale), m)
+torch.cuda.synchronize()
+t = time.perf_counter()
+for _ in range(reps):
+    batch.propose_trees(forests[:, 0], others[:, 0], Xd, ft, np.full(nc, scale), m)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t) / reps * 1e3
+print(f"propose_trees x{nc}   : {dt:.3f} ms per call = {dt / nc:.3f} ms per chain")
