@@ -216,3 +216,27 @@ def test_synthetic_prior_forests_are_valid_and_small():
     assert np.array_equal(F, synthetic.sample_prior_forests(3, 50, bounds, ft, seed=42))
     deep = synthetic.full_binary_forest(5, 8, 5, np.random.default_rng(0))
     assert ((deep["active"] == 1).sum(-1) == 63).all()
+
+
+def test_committed_bench_line_follows_the_contract():
+    """The last bench line committed under profiles/ carries every field the driver and the judge read."""
+    import glob
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r*", "bench_c3_final.json")))
+    assert files, "no committed bench line"
+    r = json.load(open(files[-1]))
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    assert base["metric"].startswith(r["metric"].split(";")[0][:40])
+    assert r["unit"] == "evals/s" and r["higher_is_better"] is True and r["scaling"] == "weak"
+    assert r["dtype"] == "f64" and r["data"] == "synthetic" and r["vs_baseline"] is None  # BASELINE.md publishes nothing
+    assert r["n_gpus"] >= 1 and r["steps"] >= 1 and r["warmup"] >= 0 and r["value"] > 0 and r["ms_per_step"] > 0
+    assert "workload" in r["config"] and "model" not in r["config"]
+    assert abs(r["value"] - r["config"]["forests_per_gpu"] * r["n_gpus"] / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
+    roof = r["roofline"]
+    assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and 0 < roof["frac"] < 1
+    assert roof["traffic"] is None or roof["traffic"] > 0
+    cpu = r["cpu_baseline"]
+    assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
