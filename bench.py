@@ -1,31 +1,41 @@
 #!/usr/bin/env python3
 """bench.py — forest-Gram + Cholesky MLL evaluations per second (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W]          # plain shell: starts its own N workers
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N ...                                  # or under an external launcher
+
+Launcher: without RANK/WORLD_SIZE in the environment this process never touches torch or the GPU; it starts
+N fresh worker processes (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set) and relays rank 0's JSON line.
+`--gpus 1` takes the same path.  Under torch.distributed.run the process IS a worker.
 
 One step = one pass of the hot path over one rank's batch of synthetic forest samples:
 leaf traversal -> N x N Gram (+ jitter) -> blocked fp64 Cholesky -> triangular solve -> log-det
 -> MLL, for every forest sample (one "eval" each), followed by the only cross-rank exchange of the
 path, the all-gather of the (B,) log-likelihoods over RCCL.  Inputs (X, y, packed forests, noise)
 are resident in HBM before the timed region; the output is the (B,) MLL vector on the device.
+The timed steps run the PRODUCTION path of the C ABI (no timing struct, no host synchronisation inside
+the library); the per-kernel breakdown comes from one separate instrumented step after the timed region.
 
 Workload (BASELINE.json configs[2], SURVEY §8d "c3"): N=4096 points, d=8 continuous features,
 m=50 trees, B=256 forest samples PER GPU drawn from the BART depth prior (alpha .95, beta 2),
 noise_b ~ U[0.05,0.15), scale 1, MLL convention of examples/mcmc/mcmc_record_mll.py:57-74.
-Weak scaling: every rank evaluates its own 256 samples (c4's sharding, at c3's per-GPU batch).
+Default = weak scaling (every rank evaluates its own 256 samples).  `--total B` = strong scaling: B samples
+in all, contiguous shards per rank (configs[3] "c4" is `--total 512 --gpus 8` = 64 per GPU); in weak mode
+with N > 1 the c4 split (512 / N per rank) is timed as a second region and reported under "c4_strong".
 """
 
 from __future__ import annotations
 
 import argparse
 import ctypes
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -33,90 +43,191 @@ if ROOT not in sys.path:
 
 F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix peak (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0
+METRIC = "forest-Gram + Cholesky MLL evals/sec at N=4096, 50 trees"
 
 
-def hbm_traffic_from_profile():
-    """HBM bytes per step of the Cholesky launch sequence, from the committed rocprofv3 PMC passes of this
-    same command (profiles/rNN/*hbm_counters*.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc
-    runs, KiB units, FETCH doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on gfx950).
-    bench.py cannot collect PMC counters itself; None when no profile is committed."""
-    import glob
-
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*hbm_counters*.json")))
-    if not files:
-        return None
-    try:
-        prof = json.load(open(files[-1]))
-        total = 0.0
-        for k in ("diag_kernel", "panel_kernel", "solve_kernel"):
-            total += 2.0 * prof["FETCH_SIZE"][k]["sum_KiB"] * 1024.0 + prof["WRITE_SIZE"][k]["sum_KiB"] * 1024.0
-        return {"bytes_per_step": total, "source": os.path.relpath(files[-1], ROOT)}
-    except Exception:
-        return None
-
-
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=4096, help="training points")
-    ap.add_argument("--batch", type=int, default=256, help="forest samples per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="forest samples per GPU (weak scaling)")
+    ap.add_argument("--total", type=int, default=0, help="forest samples in all, sharded over the GPUs (strong scaling)")
     ap.add_argument("--trees", type=int, default=50)
     ap.add_argument("--dim", type=int, default=8)
     ap.add_argument("--cpu-sample", type=int, default=3, help="forest samples timed on the host oracle (0 = skip)")
     ap.add_argument("--chunk", type=int, default=0, help="forests factorised concurrently (0 = fit HBM)")
-    return ap.parse_args()
+    ap.add_argument("--no-configs", action="store_true", help="skip the secondary per-config measurements")
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="CPU-only check of the launcher / rendezvous / gather / timing protocol (gloo, no GPU work)")
+    return ap.parse_args(argv)
 
 
-def main():
-    args = parse()
+# ---------------------------------------------------------------------------------------------
+# launcher (parent): no torch, no GPU
+# ---------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch(args) -> int:
+    n = args.gpus
+    if n < 1:
+        raise SystemExit("--gpus must be >= 1")
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BARK_BENCH_WORKER="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this host
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:  # a rank died: the others would wait in a collective for ever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------
+# helpers (workers)
+# ---------------------------------------------------------------------------------------------
+def csrc_digest() -> str:
+    """Content hash of the kernel sources (there is no .git on the GPU box): ties a committed PMC profile to a build."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "bark_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".cpp", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def hbm_traffic_from_profile(N, B, m):
+    """HBM bytes per step of the Cholesky launch sequence from a committed rocprofv3 PMC profile of this command
+    (tools/hbm_counters.sh -> profiles/rNN/*hbm_counters*.json: FETCH_SIZE and WRITE_SIZE in separate --pmc passes,
+    FETCH doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on gfx950).  bench.py cannot
+    collect PMC counters itself, so the figure is only reported when the profile was taken on THIS build of the
+    kernels (csrc digest) and this workload; otherwise null."""
+    import glob
+
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*hbm_counters*.json"))):
+        try:
+            prof = json.load(open(f))
+            meta = prof.get("meta", {})
+            if meta.get("csrc_digest") != csrc_digest() or (meta.get("N"), meta.get("B"), meta.get("m")) != (N, B, m):
+                continue
+            steps = max(int(meta.get("steps_profiled", 1)), 1)
+            total = 0.0
+            for k, v in prof["FETCH_SIZE"].items():
+                if k in meta.get("sweep_kernels", []):
+                    total += 2.0 * v["sum_KiB"] * 1024.0
+            for k, v in prof["WRITE_SIZE"].items():
+                if k in meta.get("sweep_kernels", []):
+                    total += v["sum_KiB"] * 1024.0
+            best = {"bytes_per_step": total / steps, "source": os.path.relpath(f, ROOT), "from_committed_profile": True,
+                    "csrc_digest": meta.get("csrc_digest")}
+        except Exception:
+            continue
+    return best
+
+
+class Workload:
+    """Device-resident inputs of one rank's batch + the production-path call."""
+
+    def __init__(self, N, d, m, B, seed_base, rank_offset, chunk=0, problem="unit", C=0, noise_seed=None,
+                 include_scale=False):
+        import numpy as np
+        import torch
+
+        from bark_amd import _lib, synthetic
+        from bark_amd.fitting.mll import choose_chunk
+        from bark_amd.forest import PackedForest
+
+        self.N, self.d, self.m, self.B, self.C = N, d, m, B, C
+        if problem == "unit":
+            X, y, bounds, ft = synthetic.unit_cube_problem(N, d, seed=seed_base)
+            cand = None
+        else:  # c5: mixed categorical + integer + continuous
+            X, y, bounds, ft = synthetic.mixed_problem(N, seed=seed_base)
+            cand = synthetic.mixed_problem(C, seed=seed_base + 1)[0] if C else None
+            self.d = d = X.shape[1]
+        self.X, self.y, self.ft = X, y, ft
+        self.forests = synthetic.sample_prior_forests(B, m, bounds, ft, seed=seed_base + rank_offset)
+        rng = np.random.default_rng(seed_base + 7919 * ((noise_seed if noise_seed is not None else rank_offset) + 1))
+        self.noise = rng.uniform(0.05, 0.15, size=B)
+        self.lib = lib = _lib.lib()
+        self._lib = _lib
+        self.pf = PackedForest(self.forests, ft)  # host format conversion + upload: outside every timed region
+        self.Xd = _lib.to_device(X)
+        self.yd = _lib.to_device(y.reshape(-1))
+        self.noise_d = _lib.to_device(self.noise)
+        self.scale_d = _lib.to_device(np.ones(B)) if (include_scale or C) else None
+        self.cand_d = _lib.to_device(cand) if cand is not None else None
+        dev = self.Xd.device
+        self.mll_d = torch.empty(B, dtype=torch.float64, device=dev)
+        self.info_d = torch.empty(B, dtype=torch.int32, device=dev)
+        self.mu_d = torch.empty((B, C), dtype=torch.float64, device=dev) if C else None
+        self.var_d = torch.empty((B, C), dtype=torch.float64, device=dev) if C else None
+        self.Bc = chunk or choose_chunk(B, N, C, m)
+        self.ws = torch.empty(int(lib.bark_mll_workspace_bytes(N, C, m, self.Bc)), dtype=torch.uint8, device=dev)
+        self.flags = (_lib.MLL_INCLUDE_SCALE if self.scale_d is not None else 0) | (0 if C else _lib.MLL_INCLUDE_2PI)
+        self.stream = _lib.stream_ptr()
+
+    def run(self, timing=None):
+        L = self._lib
+        L.check(self.lib.bark_mll_batched_hip(
+            L.ptr(self.pf.packed), self.pf.info_ref, L.ptr(self.Xd), self.N, self.d, L.ptr(self.yd), L.ptr(self.noise_d),
+            L.ptr(self.scale_d), None, self.flags, L.ptr(self.cand_d), self.C, L.ptr(self.mll_d), L.ptr(self.mu_d),
+            L.ptr(self.var_d), None, L.ptr(self.info_d), L.ptr(self.ws), self.ws.numel(), self.Bc,
+            ctypes.byref(timing) if timing is not None else None, self.stream))
+        return self.mll_d
+
+    def device_ms(self, reps, warm=1):
+        """Average duration of one production-path call from HIP events on the launch stream."""
+        import torch
+
+        for _ in range(warm):
+            self.run()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        e[0].record()
+        for i in range(reps):
+            self.run()
+            e[i + 1].record()
+        torch.cuda.synchronize()
+        spans = sorted(e[i].elapsed_time(e[i + 1]) for i in range(reps))
+        return sum(spans) / reps, spans[len(spans) // 2]
+
+    def check(self):
+        import numpy as np
+
+        assert int(self.info_d.abs().max().item()) == 0, "a kernel matrix was not positive definite"
+        host = self.mll_d.cpu().numpy()
+        assert np.isfinite(host).all()
+        return host
+
+
+def timed_region(wl, steps, warmup, world, dist, gather):
+    """W warm-up steps, then exactly K steps between barrier + synchronize fences; max over ranks."""
     import torch
-    import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    from bark_amd import _lib, synthetic
-    from bark_amd.distributed import gather_mll
-    from bark_amd.fitting.mll import choose_chunk
-    from bark_amd.forest import PackedForest
-
-    N, B, m, d = args.n, args.batch, args.trees, args.dim
-    # ---- synthetic inputs (SURVEY §8d c3): same X, y on every rank; rank r owns forests r*B .. r*B+B-1
-    X, y, bounds, ft = synthetic.unit_cube_problem(N, d, seed=N)
-    forests = synthetic.sample_prior_forests(B, m, bounds, ft, seed=N + rank * B)
-    noise = np.random.default_rng(N + 7919 * (rank + 1)).uniform(0.05, 0.15, size=B)
-
-    lib = _lib.lib()
-    pf = PackedForest(forests, ft)  # host format conversion + upload: outside the timed region
-    Xd = _lib.to_device(X)
-    yd = _lib.to_device(y.reshape(-1))
-    noise_d = _lib.to_device(noise)
-    mll_d = torch.empty(B, dtype=torch.float64, device=Xd.device)
-    info_d = torch.empty(B, dtype=torch.int32, device=Xd.device)
-    Bc = args.chunk or choose_chunk(B, N, 0, m)
-    ws = _lib.workspace(int(lib.bark_mll_workspace_bytes(N, 0, m, Bc)))
-    flags = _lib.MLL_INCLUDE_2PI
-    stream = _lib.stream_ptr()
-    timing = _lib.MllTiming()
-    tsum = dict(total_ms=0.0, gram_ms=0.0, chol_ms=0.0, diag_ms=0.0, panel_ms=0.0, solve_ms=0.0)
-
-    def step(timed: bool):
-        _lib.check(lib.bark_mll_batched_hip(
-            _lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(yd), _lib.ptr(noise_d), None, None, flags,
-            None, 0, _lib.ptr(mll_d), None, None, None, _lib.ptr(info_d), _lib.ptr(ws), ws.numel(), Bc,
-            ctypes.byref(timing) if timed else None, stream))
-        if timed:  # HIP-event spans of this step's launches, recorded on the launch stream
-            for k in tsum:
-                tsum[k] += getattr(timing, k)
-        return gather_mll(mll_d, B * world) if world > 1 else mll_d
 
     def fence():
         torch.cuda.synchronize()
@@ -124,128 +235,157 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
+    out = None
+    for _ in range(warmup):
+        out = gather(wl.run())
     fence()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * steps)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        all_mll = step(True)
+    for i in range(steps):
+        ev[2 * i].record()      # HIP events on the launch stream, around the library call only
+        mll = wl.run()
+        ev[2 * i + 1].record()
+        out = gather(mll)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=Xd.device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=wl.Xd.device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    nocheck = os.environ.get("BARK_BENCH_NOCHECK") == "1"  # tuning aid for timing-only ablation builds
-    assert nocheck or int(info_d.abs().max().item()) == 0, "a kernel matrix was not positive definite"
-    mll_host = all_mll.cpu().numpy()
-    assert nocheck or np.isfinite(mll_host).all()
+    call_ms = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(steps)) / steps
+    return elapsed, call_ms, out
 
-    # ---- the standalone Gram kernel (forest.py:78-98 API path), HBM-write bound: measured outside the timed
-    # region on 16 forests, full N x N fp64 output each (in the MLL sweep the Gram is generated inside the
-    # panel kernel and never written, so the sweep itself has no Gram stage to price)
-    gram_probe = None
+
+# ---------------------------------------------------------------------------------------------
+# worker
+# ---------------------------------------------------------------------------------------------
+def selftest_worker(args, world, rank):
+    """Launcher / rendezvous / gather / timing protocol on CPU (gloo): what a worker does around the GPU work."""
+    import torch
+    import torch.distributed as dist
+
+    from bark_amd.distributed import gather_mll, shard_range
+
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    total = args.total or args.batch * world
+    lo, hi = shard_range(total, rank, world) if args.total else (rank * args.batch, (rank + 1) * args.batch)
+    local = torch.arange(lo, hi, dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    full = gather_mll(local, total) if world > 1 else local
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ok = bool((full == torch.arange(total, dtype=torch.float64)).all())
     if rank == 0:
-        Bg = min(16, B)
-        sub = _lib.PackInfo.from_buffer_copy(pf.info)
-        sub.B = Bg
-        leaves = torch.empty((Bg, int(lib.bark_leaf_words(ctypes.byref(sub))), int(lib.bark_leaf_npad(N))),
-                             dtype=torch.int32, device=Xd.device)
-        Kg = torch.empty((Bg, N, N), dtype=torch.float64, device=Xd.device)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 8
-        for it in range(reps + 1):
-            if it == 1:
-                e0.record()
-            _lib.check(lib.bark_leaf_codes_hip(_lib.ptr(pf.packed), ctypes.byref(sub), _lib.ptr(Xd), N, d,
-                                               _lib.ptr(leaves), stream))
-            _lib.check(lib.bark_gram_from_leaves_hip(_lib.ptr(leaves), N, _lib.ptr(leaves), N, ctypes.byref(sub), None,
-                                                     None, None, _lib.ptr(Kg), N, N * N, stream))
-        e1.record()
-        torch.cuda.synchronize()
-        g_ms = e0.elapsed_time(e1) / reps
-        g_bytes = Bg * (8.0 * N * N + 4.0 * m * 2 * N)  # SURVEY §8d bytes_gram per matrix
-        gram_probe = {"bound": "hbm", "forests": Bg, "algorithmic_bytes": g_bytes, "ms": g_ms,
-                      "leaf_code": "one-hot bits" if lib.bark_leaf_encoding(ctypes.byref(sub)) == 1 else "packed bytes",
-                      "leaf_code_words": int(lib.bark_leaf_words(ctypes.byref(sub))),
-                      "achieved_GBs": g_bytes / (g_ms * 1e-3) / 1e9, "peak_GBs": HBM_PEAK_GBS,
-                      "frac": g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        del Kg, leaves
+        print(json.dumps({"selftest": "launcher", "n_gpus": world, "ranks_reached": world, "gather_ok": ok,
+                          "total": total, "local": hi - lo, "scaling": "strong" if args.total else "weak",
+                          "launched_by": "bench.py" if os.environ.get("BARK_BENCH_WORKER") else "external"}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
 
-    # ---- informational only: the leaf-space evaluation of the SAME MLLs (R x R system over the leaves instead
-    # of the N x N matrix).  It does not do the Gram + Cholesky work the metric counts and is not part of `value`.
-    leaf_probe = None
-    if rank == 0:
-        lws = torch.empty(int(lib.bark_mll_leafspace_workspace_bytes(N, int(pf.info.max_bits), m, B, 0)), dtype=torch.uint8,
-                          device=Xd.device)
-        lmll = torch.empty(B, dtype=torch.float64, device=Xd.device)
-        linfo = torch.empty(B, dtype=torch.int32, device=Xd.device)
-        l0, l1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        lreps = 5
-        for it in range(lreps + 1):
-            if it == 1:
-                l0.record()
-            _lib.check(lib.bark_mll_leafspace_hip(_lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(yd),
-                                                  _lib.ptr(noise_d), None, flags, None, 0, _lib.ptr(lmll), None, None,
-                                                  _lib.ptr(linfo), _lib.ptr(lws), lws.numel(), B, stream))
-        l1.record()
-        torch.cuda.synchronize()
-        l_ms = l0.elapsed_time(l1) / lreps
-        dense_local = mll_d.cpu().numpy()
-        leaf_local = lmll.cpu().numpy()
-        leaf_probe = {"note": "exact Woodbury/determinant-lemma evaluation over the forest's leaves; NOT the benchmark "
-                              "metric (no N x N Gram, no N^3/3 Cholesky)",
-                      "leaves_per_forest_max": int(pf.info.max_bits), "ms_per_%d_evals" % B: l_ms,
-                      "evals_per_s": B / (l_ms * 1e-3),
-                      "max_rel_diff_vs_dense": float(np.max(np.abs(leaf_local - dense_local) / np.abs(dense_local)))}
-        del lws
 
-    # one chain of the sampler on this workload's data: per-tree proposal, accept, noise/scale
-    # proposal and the rebuild of the resident inverse — secondary numbers, never `value`
-    chain_probe = None
-    if rank == 0:
-        from bark_amd.fitting import ChainState
+def worker(args) -> int:
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.selftest_launcher:
+        return selftest_worker(args, world, rank)
 
-        def wall_ms(fn, reps):
-            fn()
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            for _ in range(reps):
-                fn()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t) / reps * 1e3
+    import numpy as np
+    import torch
+    import torch.distributed as dist
 
-        chain = ChainState.from_forest(forests[0], float(noise[0]), 1.0, Xd, y, ft)
-        old_tree, new_tree = forests[0][0], forests[-1][-1]  # any two trees of this rank's forests
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    backend = os.environ.get("BARK_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"--gpus {world} but only {ndev} devices (set BARK_BENCH_BACKEND=gloo to share a GPU in a dry run)")
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    if world > 1:
+        import datetime
 
-        def swap_there_and_back():
-            chain.propose_tree(old_tree, new_tree, Xd, ft, 1.0, m)
-            chain.accept()
-            chain.propose_tree(new_tree, old_tree, Xd, ft, 1.0, m)
-            chain.accept()
+        kw = dict(rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", dev_index)
+        dist.init_process_group(backend, **kw)
 
-        def rebuild():
-            chain.propose_noise_scale(forests[0], float(noise[0]), 1.0, Xd, ft)
-            chain.accept()
+    from bark_amd import _lib
+    from bark_amd.distributed import gather_mll, shard_range
 
-        t_prop = wall_ms(lambda: chain.propose_tree(old_tree, new_tree, Xd, ft, 1.0, m), 50)
-        t_pair = wall_ms(swap_there_and_back, 25) / 2
-        t_ns = wall_ms(lambda: chain.propose_noise_scale(forests[0], float(noise[0]), 1.0, Xd, ft), 20)
-        t_rebuild = wall_ms(rebuild, 10)
-        chain_probe = {"note": "one chain, N=%d, m=%d, wall time per call incl. host (bark_sampler.py:226-272)" % (N, m),
-                       "tree_proposal_ms": t_prop, "tree_proposal_plus_accept_ms": t_pair,
-                       "noise_scale_proposal_ms": t_ns, "noise_scale_proposal_plus_rebuild_ms": t_rebuild}
-        del chain
+    N, m, d = args.n, args.trees, args.dim
+    strong = args.total > 0
+    if strong:
+        lo, hi = shard_range(args.total, rank, world)
+        B, offset, total = hi - lo, lo, args.total
+        if B < 1:
+            raise SystemExit("--total smaller than the number of GPUs")
+    else:
+        B, offset, total = args.batch, rank * args.batch, args.batch * world
+
+    def make_gather(total_):
+        if world == 1:
+            return lambda t: t
+        if backend == "nccl":
+            return lambda t: gather_mll(t, total_)
+        return lambda t: gather_mll(t.cpu(), total_)  # dry run on a shared GPU: gloo moves host tensors
+
+    # ---- synthetic inputs (SURVEY §8d c3): same X, y on every rank; rank r owns forests offset .. offset+B-1
+    wl = Workload(N, d, m, B, seed_base=N, rank_offset=offset, chunk=args.chunk, noise_seed=rank)
+    elapsed, call_ms, all_mll = timed_region(wl, args.steps, args.warmup, world, dist, make_gather(total))
+    mll_host = wl.check()
+    assert all_mll.shape[0] == total and bool(torch.isfinite(all_mll).all())
+
+    # ---- c4 split (BASELINE configs[3]: 512 samples over the GPUs) as a second timed region in weak mode, N > 1
+    c4 = None
+    if world > 1 and not strong and N == 4096:
+        lo, hi = shard_range(512, rank, world)
+        wl4 = Workload(N, d, m, hi - lo, seed_base=N, rank_offset=lo, noise_seed=rank)
+        e4, call4, out4 = timed_region(wl4, args.steps, args.warmup, world, dist, make_gather(512))
+        wl4.check()
+        c4 = {"workload": "c4: 512 forest samples sharded over %d GPUs (%d per GPU)" % (world, hi - lo), "scaling": "strong",
+              "value": 512 * args.steps / e4, "unit": "evals/s", "ms_per_step": e4 / args.steps * 1e3,
+              "call_ms_rank0": call4}
+        del wl4
+    if world > 1:
+        dist.barrier()  # every rank leaves here; rank 0's untimed extras below run with no peer waiting in a collective
+        dist.destroy_process_group()
+    if rank != 0:
+        return 0
 
     steps = args.steps
-    evals = B * world * steps
-    value = evals / elapsed
-    per_step = {k: v / steps for k, v in tsum.items()}
+    value = total * steps / elapsed
     chol_flops = B * N**3 / 3.0  # algorithmic flops of one launch sequence (SURVEY §8d flops_chol x B)
-    chol_tflops = chol_flops / (per_step["chol_ms"] * 1e-3) / 1e12
-    traffic = hbm_traffic_from_profile()
+    chol_tflops = chol_flops / (call_ms * 1e-3) / 1e12
+    traffic = hbm_traffic_from_profile(N, B, m)
+    lib = wl.lib
+
+    # ---- one instrumented step (outside the timed region): per-kernel HIP-event spans inside the library
+    timing = _lib.MllTiming()
+    wl.run(timing)
+    breakdown = {k: round(float(getattr(timing, k)), 3) for k in ("total_ms", "gram_ms", "chol_ms", "diag_ms", "panel_ms", "solve_ms")}
+    kern = {}
+    for name, ms_key, n_key, fl_key in (("panel_kernel", "panel_ms", "n_panel_launches", "panel_flops"),
+                                        ("solve_kernel", "solve_ms", "n_solve_launches", "solve_flops"),
+                                        ("diag_kernel", "diag_ms", "n_diag_launches", None)):
+        nl = int(getattr(timing, n_key))
+        ms = float(getattr(timing, ms_key))
+        kern[name] = {"launches_per_step": nl, "avg_ms": ms / max(nl, 1)}
+        if fl_key:
+            kern[name]["executed_tflops"] = float(getattr(timing, fl_key)) / (max(ms, 1e-9) * 1e-3) / 1e12
+
     result = {
-        "metric": "forest-Gram + Cholesky MLL evals/sec at N=4096, 50 trees",
+        "metric": METRIC,
         "value": value,
         "unit": "evals/s",
         "n_gpus": world,
@@ -253,79 +393,201 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": "c3: N=%d d=%d m=%d, %d prior forest samples per GPU (BASELINE configs[2]; "
-                        "sharding of configs[3]), noise U[0.05,0.15), mcmc_record_mll convention" % (N, d, m, B),
-            "N": N, "d": d, "trees": m, "forests_per_gpu": B, "chunk": Bc, "parallelism": "samples/%d" % world,
+            "workload": ("c4: N=%d d=%d m=%d, %d prior forest samples sharded over %d GPUs" % (N, d, m, total, world)) if strong else
+                        ("c3: N=%d d=%d m=%d, %d prior forest samples per GPU (BASELINE configs[2]; sharding of "
+                         "configs[3])" % (N, d, m, B)) + ", noise U[0.05,0.15), mcmc_record_mll convention",
+            "N": N, "d": d, "trees": m, "forests_per_gpu": B, "forests_total": total, "chunk": wl.Bc,
+            "parallelism": "samples/%d" % world, "launched_by": "bench.py" if os.environ.get("BARK_BENCH_WORKER") else "external",
+            "timed_path": "production (timing=NULL, no host sync inside the library)",
         },
         "roofline": {
             "bound": "mfma",
-            "kernel": "Cholesky launch sequence per step (diag_kernel + panel_kernel + solve_kernel; panel_kernel "
-                      "dominates). diag_kernel(j) runs beside panel_kernel(j) on a helper stream, so the per-kernel "
-                      "event spans below overlap and do not add up to chol_ms",
+            "kernel": "Cholesky launch sequence of one step (the fp64 MFMA panel kernel dominates); `achieved` = algorithmic "
+                      "B*N^3/3 flops / average duration of the library call, HIP events on the launch stream around every "
+                      "timed step",
             "achieved": chol_tflops,
             "peak": F64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": chol_tflops / F64_MFMA_PEAK_TFLOPS,
             "traffic": traffic["bytes_per_step"] if traffic else None,
-            "traffic_unit": "bytes of HBM traffic per step (one Cholesky launch sequence, 256 evals)",
-            "traffic_source": traffic["source"] if traffic else None,
+            "traffic_unit": "bytes of HBM traffic per step (one Cholesky launch sequence)",
+            "traffic_source": traffic if traffic else "no committed PMC profile matches this build (csrc digest %s) "
+                                                      "and workload" % csrc_digest(),
             "algorithmic_flops_per_step": chol_flops,
-            "ms_per_step": {k: round(v, 3) for k, v in per_step.items()},
-            "panel_kernel": {
-                "launches_per_step": int(timing.n_panel_launches),
-                "avg_ms": per_step["panel_ms"] / max(int(timing.n_panel_launches), 1),
-                "executed_tflops": timing.panel_flops / (max(per_step["panel_ms"], 1e-9) * 1e-3) / 1e12,
-            },
-            "solve_kernel": {
-                "launches_per_step": int(timing.n_solve_launches),
-                "avg_ms": per_step["solve_ms"] / max(int(timing.n_solve_launches), 1),
-                "executed_tflops": timing.solve_flops / (max(per_step["solve_ms"], 1e-9) * 1e-3) / 1e12,
-            },
-            "diag_kernel": {
-                "launches_per_step": int(timing.n_diag_launches),
-                "avg_ms": per_step["diag_ms"] / max(int(timing.n_diag_launches), 1),
-            },
-            "gram_stage_ms_per_step": round(per_step["gram_ms"], 3),
-            "gram_kernel": gram_probe,
+            "call_ms": call_ms,
+            "instrumented_step_ms": breakdown,
+            "kernels": kern,
         },
-        "leafspace_probe": leaf_probe,
-        "chain_step_probe": chain_probe,
     }
+    if c4:
+        result["c4_strong"] = c4
 
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
-        # the oracle (checker) timed on this box's host cores on a bounded sample of the same workload
+    if world == 1:
+        extras(args, wl, result, mll_host)
+    print(json.dumps(result), flush=True)
+    return 0
+
+
+def extras(args, wl, result, mll_host):
+    """Rank 0, N = 1 only, all outside the timed region: Gram-kernel roofline, the other BASELINE configs,
+    informational probes, and the CPU baseline."""
+    import numpy as np
+    import torch
+
+    from bark_amd import _lib
+
+    lib, N, m, d, B = wl.lib, wl.N, wl.m, wl.d, wl.B
+    stream = wl.stream
+
+    # ---- the standalone Gram kernel (forest.py:78-98 API path), HBM-write bound: 16 forests, full N x N fp64 output
+    Bg = min(16, B)
+    sub = _lib.PackInfo.from_buffer_copy(wl.pf.info)
+    sub.B = Bg
+    leaves = torch.empty((Bg, int(lib.bark_leaf_words(ctypes.byref(sub))), int(lib.bark_leaf_npad(N))),
+                         dtype=torch.int32, device=wl.Xd.device)
+    Kg = torch.empty((Bg, N, N), dtype=torch.float64, device=wl.Xd.device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 8
+    for it in range(reps + 1):
+        if it == 1:
+            e0.record()
+        _lib.check(lib.bark_leaf_codes_hip(_lib.ptr(wl.pf.packed), ctypes.byref(sub), _lib.ptr(wl.Xd), N, d,
+                                           _lib.ptr(leaves), stream))
+        _lib.check(lib.bark_gram_from_leaves_hip(_lib.ptr(leaves), N, _lib.ptr(leaves), N, ctypes.byref(sub), None,
+                                                 None, None, _lib.ptr(Kg), N, N * N, stream))
+    e1.record()
+    torch.cuda.synchronize()
+    g_ms = e0.elapsed_time(e1) / reps
+    g_bytes = Bg * (8.0 * N * N + 4.0 * m * 2 * N)  # SURVEY §8d bytes_gram per matrix
+    result["roofline"]["gram_kernel"] = {
+        "bound": "hbm", "forests": Bg, "algorithmic_bytes": g_bytes, "ms": g_ms,
+        "leaf_code": "one-hot bits" if lib.bark_leaf_encoding(ctypes.byref(sub)) == 1 else "packed bytes",
+        "leaf_code_words": int(lib.bark_leaf_words(ctypes.byref(sub))),
+        "achieved_GBs": g_bytes / (g_ms * 1e-3) / 1e9, "peak_GBs": HBM_PEAK_GBS,
+        "frac": g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    del Kg, leaves
+
+    # ---- the other BASELINE configs and the small-batch regime (device time of the production call, HIP events)
+    if not args.no_configs and N == 4096:
+        cfgs = []
+
+        def entry(name, w, reps_):
+            avg, med = w.device_ms(reps_)
+            w.check()
+            flops = w.B * (w.N**3 / 3.0 + (float(w.N) * w.N * w.C if w.C else 0.0))
+            tf = flops / (med * 1e-3) / 1e12
+            cfgs.append({"config": name, "N": w.N, "B": w.B, "C": w.C, "device_ms": med, "device_ms_mean": avg,
+                         "evals_per_s": w.B / (med * 1e-3), "tflops": tf, "frac_of_f64_mfma_peak": tf / F64_MFMA_PEAK_TFLOPS})
+
+        entry("c2: N=1024 d=8 m=50, single forest", Workload(1024, 8, m, 1, 1024, 0), 20)
+        entry("c4 per-GPU share: N=4096, 64 forests", Workload(4096, d, m, 64, N, 0), 5)
+        entry("small batch: N=4096, 16 forests", Workload(4096, d, m, 16, N, 0), 5)
+        entry("lone matrix: N=4096, 1 forest", Workload(4096, d, m, 1, N, 0), 10)
+        torch.cuda.empty_cache()
+        w5 = Workload(16384, 12, m, 1, 16384, 0, problem="mixed", include_scale=True)
+        entry("c5 MLL: N=16384 mixed cat+int+cont, single forest", w5, 3)
+        del w5
+        torch.cuda.empty_cache()
+        w5p = Workload(16384, 12, m, 1, 16384, 0, problem="mixed", C=10000)
+        entry("c5 posterior: N=16384 mixed, 10^4 candidates (mu, var), single forest", w5p, 3)
+        del w5p
+        torch.cuda.empty_cache()
+        # Gram kernel alone at c2 (BASELINE.md §3 asks for Gram GB/s per config)
+        w2 = Workload(1024, 8, m, 1, 1024, 0)
+        lv = torch.empty((1, int(lib.bark_leaf_words(w2.pf.info_ref)), int(lib.bark_leaf_npad(1024))), dtype=torch.int32,
+                         device=wl.Xd.device)
+        K2 = torch.empty((1, 1024, 1024), dtype=torch.float64, device=wl.Xd.device)
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for it in range(21):
+            if it == 1:
+                a0.record()
+            _lib.check(lib.bark_gram_from_leaves_hip(_lib.ptr(lv), 1024, _lib.ptr(lv), 1024, w2.pf.info_ref, None, None, None,
+                                                     _lib.ptr(K2), 1024, 1024 * 1024, stream))
+        a1.record()
+        torch.cuda.synchronize()
+        g2 = a0.elapsed_time(a1) / 20
+        cfgs.append({"config": "c2 Gram kernel alone: N=1024, single forest (launch-latency bound: 8.4 MB of output)",
+                     "device_ms": g2, "achieved_GBs": (8.0 * 1024 * 1024 + 4.0 * m * 2048) / (g2 * 1e-3) / 1e9})
+        del w2, lv, K2
+        result["configs"] = cfgs
+
+    # ---- informational only: the leaf-space evaluation of the SAME MLLs (R x R system over the leaves instead
+    # of the N x N matrix).  It does not do the Gram + Cholesky work the metric counts and is not part of `value`.
+    pf = wl.pf
+    lws = torch.empty(int(lib.bark_mll_leafspace_workspace_bytes(N, int(pf.info.max_bits), m, B, 0)), dtype=torch.uint8,
+                      device=wl.Xd.device)
+    lmll = torch.empty(B, dtype=torch.float64, device=wl.Xd.device)
+    linfo = torch.empty(B, dtype=torch.int32, device=wl.Xd.device)
+    l0, l1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    lreps = 5
+    for it in range(lreps + 1):
+        if it == 1:
+            l0.record()
+        _lib.check(lib.bark_mll_leafspace_hip(_lib.ptr(pf.packed), pf.info_ref, _lib.ptr(wl.Xd), N, d, _lib.ptr(wl.yd),
+                                              _lib.ptr(wl.noise_d), None, wl.flags, None, 0, _lib.ptr(lmll), None, None,
+                                              _lib.ptr(linfo), _lib.ptr(lws), lws.numel(), B, stream))
+    l1.record()
+    torch.cuda.synchronize()
+    l_ms = l0.elapsed_time(l1) / lreps
+    leaf_local = lmll.cpu().numpy()
+    result["leafspace_probe"] = {
+        "note": "exact Woodbury/determinant-lemma evaluation over the forest's leaves; NOT the benchmark metric "
+                "(no N x N Gram, no N^3/3 Cholesky)",
+        "leaves_per_forest_max": int(pf.info.max_bits), "ms_per_%d_evals" % B: l_ms, "evals_per_s": B / (l_ms * 1e-3),
+        "max_rel_diff_vs_dense": float(np.max(np.abs(leaf_local - mll_host) / np.abs(mll_host)))}
+    del lws
+
+    # ---- the oracle (checker) timed on this box's host cores on a bounded sample of the same workload
+    if args.cpu_sample > 0:
         from oracle import oracle as orc
 
+        cores = len(os.sched_getaffinity(0))
         ns = min(args.cpu_sample, B)
+        F, noise = wl.forests, wl.noise
         t1 = time.perf_counter()
-        ref = orc.batched_mll(forests[:ns], noise[:ns], None, X, y, ft, include_scale=False, include_2pi=True)
+        ref = orc.batched_mll(F[:ns], noise[:ns], None, wl.X, wl.y, wl.ft, include_scale=False, include_2pi=True)
         cpu_s = time.perf_counter() - t1
         t2 = time.perf_counter()
-        orc.batched_mll(forests[:ns], noise[:ns], None, X, y, ft, include_scale=False, include_2pi=True, cholesky=True)
+        orc.batched_mll(F[:ns], noise[:ns], None, wl.X, wl.y, wl.ft, include_scale=False, include_2pi=True, cholesky=True)
         chol_s = time.perf_counter() - t2
         rel = float(np.max(np.abs(mll_host[:ns] - ref) / np.abs(ref)))
         assert np.allclose(mll_host[:ns], ref, rtol=1e-9, atol=1e-8), (mll_host[:ns], ref)
+        single = None
+        try:  # the reference's own configuration is single-threaded numba + whatever LAPACK threads numpy has
+            from threadpoolctl import threadpool_limits
+
+            with threadpool_limits(limits=1):
+                t3 = time.perf_counter()
+                orc.batched_mll(F[:1], noise[:1], None, wl.X, wl.y, wl.ft, include_scale=False, include_2pi=True)
+                one_s = time.perf_counter() - t3
+            single = {"value": 1.0 / one_s, "unit": "evals/s", "cores": 1,
+                      "sample": "1 forest sample, every stage on one thread (LAPACK limited by threadpoolctl), %.1f s" % one_s}
+        except Exception as exc:  # pragma: no cover
+            single = {"error": repr(exc)}
         result["cpu_baseline"] = {
             "value": ns / cpu_s,
             "unit": "evals/s",
-            "cores": len(os.sched_getaffinity(0)),
+            "cores": cores,
             "kind": "port",
             "sample": "%d of the %d forest samples of this workload (N=%d): C leaf walk + N*N*m compare-count Gram "
-                      "(1 thread, as the reference) + numpy.linalg.inv + slogdet (LAPACK threads = cores), %.1f s"
-                      % (ns, B, N, cpu_s),
+                      "(1 thread, as the reference) + numpy.linalg.inv + slogdet (LAPACK on all %d cores), %.1f s"
+                      % (ns, B, N, cores, cpu_s),
             "cholesky_variant_evals_per_s": ns / chol_s,
+            "single_thread": single,
             "gpu_vs_oracle_max_rel_err": rel,
         }
-    if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
-        dist.barrier()  # rank 0 ran the untimed probes above; leave together
-        dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
+        sys.exit(worker(args))
+    sys.exit(launch(args))
 
 
 if __name__ == "__main__":

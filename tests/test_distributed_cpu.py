@@ -87,3 +87,54 @@ def test_gather_mll_world2_gloo(total):
     for rank in (0, 1):
         assert np.allclose(mixes[rank][0], want_mu, rtol=1e-12, atol=1e-14)
         assert np.allclose(mixes[rank][1], want_var, rtol=1e-10, atol=1e-13)
+
+
+def _run_bench(argv, env_extra=None, timeout=180):
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    out = subprocess.run([sys.executable, *argv], cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout  # exactly ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_bench_launches_its_own_workers_from_a_plain_shell(gpus):
+    """`python bench.py --gpus N` with no launcher around it: the parent (no torch, no GPU) starts N fresh workers,
+    they rendezvous on 127.0.0.1, gather the per-rank MLL blocks and MAX-reduce the clock; rank 0 prints the line."""
+    r = _run_bench(["bench.py", "--gpus", str(gpus), "--selftest-launcher"])
+    assert r["ranks_reached"] == gpus and r["gather_ok"] and r["launched_by"] == "bench.py"
+    assert r["scaling"] == "weak" and r["total"] == 256 * gpus and r["local"] == 256
+
+
+def test_bench_strong_scaling_shards_c4():
+    """BASELINE configs[3]: 512 forest samples over the GPUs, contiguous blocks (forest.py:92-98 loop order)."""
+    r = _run_bench(["bench.py", "--gpus", "2", "--total", "512", "--selftest-launcher"])
+    assert r["scaling"] == "strong" and r["total"] == 512 and r["local"] == 256 and r["gather_ok"]
+
+
+def test_bench_runs_as_a_worker_under_torch_distributed_run():
+    """The form the driver uses for N > 1: an external launcher provides RANK / WORLD_SIZE."""
+    r = _run_bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--selftest-launcher"])
+    assert r["ranks_reached"] == 2 and r["gather_ok"] and r["launched_by"] == "external"
+
+
+def test_bench_parent_never_imports_torch():
+    """The launcher must not initialise the GPU before the workers exist (a forked/exec'd GPU context kills the box)."""
+    import ast
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tree = ast.parse(open(os.path.join(root, "bench.py")).read())
+    top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
+    names = {a.name.split(".")[0] for n in top if isinstance(n, ast.Import) for a in n.names}
+    names |= {n.module.split(".")[0] for n in top if isinstance(n, ast.ImportFrom) and n.module}
+    assert "torch" not in names and "bark_amd" not in names and "numpy" not in names
+    launch = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "launch")
+    assert not any(isinstance(n, (ast.Import, ast.ImportFrom)) for n in ast.walk(launch))
