@@ -14,7 +14,9 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbarkhip.so")
+# $BARK_LIB_PATH points the binding at another build of the same ABI (A/B of tuning variants: tools/ab/) without
+# ever overwriting the in-tree product library.
+LIB_PATH = os.environ.get("BARK_LIB_PATH") or os.path.join(_HERE, "csrc", "libbarkhip.so")
 
 BARK_OK = 0
 BARK_ERR_ARG, BARK_ERR_TREE, BARK_ERR_CATEGORICAL, BARK_ERR_HIP, BARK_ERR_WORKSPACE = 1, 2, 3, 4, 5

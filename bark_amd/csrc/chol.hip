@@ -11,7 +11,7 @@
 //   diag_kernel  (1 workgroup / matrix)   D = P_jj - U[j-1,j]'U[j-1,j]; U_jj = chol(D); W_j = U_jj^-1;
 //                                         z_j = W_j' y_j; logdet += 2 sum log diag; quad += |z_j|^2
 //        ||  (concurrently, helper stream)
-//   panel_kernel (1 workgroup / 128x128 tile) T[j,i] = A[j,i] - sum_{k<j} U[k,j]' U[k,i]   (fp64 MFMA, K = 128 j)
+//   row_kernel   (1 workgroup / 128x128 tile) T[j,i] = A[j,i] - sum_{k<j} U[k,j]' U[k,i]   (fp64 MFMA, K = 128 j)
 //                                         plus the partial diagonal tile P_{j+1,j+1} (same sum, k < j).
 //                                         Panels are staged by LDS-DMA; in MLL-only sweeps A[j,i] is generated
 //                                         in the epilogue from the leaf codes (the Gram is never materialised).
@@ -71,13 +71,6 @@ constexpr int LDS_LD = NB + 16;  // padded row (doubles)
 constexpr int STAGE = 2 * BK * LDS_LD;  // A rows then B rows, doubles
 constexpr int GEMM_LDS_DOUBLES = 2 * STAGE;
 constexpr int THREADS = 256;
-#ifndef BARK_PANEL_DMA
-#define BARK_PANEL_DMA 1
-#endif
-// timing-only ablation builds of the panel loop (results invalid): 3 = no DMA issue, 4 = no DMA, no barrier
-#ifndef BARK_ABLATE
-#define BARK_ABLATE 0
-#endif
 
 struct Lane {
     int wr, wc, lr, lk;
@@ -194,14 +187,10 @@ __device__ __forceinline__ void gemm_kmajor_dma(f64x4 (&acc)[4][4], const double
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-#if BARK_ABLATE < 3
         if (kt + 1 < nk) stage_dma(A, lda, B, ldb, kt + 1, lds + ((kt + 1) & 1) * STAGE, wave, lane);
-#endif
         mma_stage(acc, lds + (kt & 1) * STAGE, q);
-#if BARK_ABLATE < 4
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-#endif
     }
 }
 
@@ -327,10 +316,11 @@ constexpr int SB = 16;          // sub-block edge
 constexpr int NSB = NB / SB;    // 8 sub-blocks per edge
 constexpr int TS = SB + 1;      // row stride of the per-wave 16x16 transpose scratch
 constexpr int NBLK = NSB * (NSB + 1) / 2;  // 36 stored sub-blocks (upper block triangle)
+constexpr int NSB_ROWS = NSB;             // 16-row tiles per block (y-update partials)
 
 // S is stored as a packed upper block triangle: sub-block (rb, cb), rb <= cb, is a contiguous
 // row-major 16x16 (2 KiB), so the whole 128x128 factor image takes 72 KiB instead of 136 KiB and the
-// kernel can share a CU with a panel workgroup (it runs beside panel_kernel on a helper stream).
+// kernel can share a CU with a row workgroup (it runs beside row_kernel, which is on a helper stream).
 // A k-major MFMA operand read (4 rows x 16 columns) is one contiguous 512-B span: conflict-free.
 __device__ __forceinline__ int blk_off(int rb, int cb) { return (rb * NSB - (rb * (rb - 1)) / 2 + (cb - rb)) * SB * SB; }
 __device__ __forceinline__ double &s_at(double *S, int r, int c) {  // element (r, c), r/16 <= c/16
@@ -583,32 +573,16 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// panel_kernel: T[j,i] = A[j,i] - sum_{k<j} U[k,j]' U[k,i]  for i > j (all column blocks), and the
-// partial diagonal tile (j+1, j+1).  1-D grid, (matrix, tile) from xcd_map.
+// Tile helpers shared by the row kernels.
 // ---------------------------------------------------------------------------------------------
-template <int GEN>  // 0: A tile read from HBM; 1 + LeafRep: A generated from the leaf codes (bytes8 / bytes7 / bits)
-__global__ __launch_bounds__(THREADS, 2) void panel_kernel(Mats p, int j, int n_right, int n_tiles) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int tid = threadIdx.x;
-    int b, t;
-    if (!xcd_map(blockIdx.x, n_tiles, p.Bc, b, t)) return;
-    const Lane q = lane_of(tid);
-    double *Ab = p.A + (size_t)b * p.bstride;
-    int rb, cb;
-    if (t < n_right) {
-        rb = j;
-        cb = j + 1 + t;
-    } else {
-        rb = cb = j + 1;
-    }
-    f64x4 acc[4][4];
-    zero_acc(acc);
-#if BARK_PANEL_DMA
-    gemm_kmajor_dma(acc, Ab + (size_t)rb * NB, p.ld, Ab + (size_t)cb * NB, p.ld, j * NB, lds, tid, q);
-#else
-    gemm_kmajor(acc, Ab + (size_t)rb * NB, p.ld, Ab + (size_t)cb * NB, p.ld, j * NB, lds, tid, q);
-#endif
-    double *tile = Ab + (size_t)rb * NB * p.ld + (size_t)cb * NB;
+// tile := A[rb,cb] - acc  (acc holds sum_{k<j} U[k,rb]'U[k,cb] in the MFMA D layout).
+// GEN == 0: the A tile is read from HBM; GEN == 1 + LeafRep: it is generated from the leaf codes (bytes8 / bytes7 /
+// bits): A[r][c] = [scale *] ((1/m) * #{t: leaf ids agree} [- shift])  (+ jitter on the global diagonal), identity in
+// the padding — the Gram matrix is never written to or read from HBM.  Uses (and leaves dirty) the first
+// 2 * nW * 128 dwords of LDS when GEN > 0; all 256 threads; the caller's GEMM ended with a barrier.
+template <int GEN>
+__device__ __forceinline__ void form_tile(const f64x4 (&acc)[4][4], const Mats &p, int b, int rb, int cb, double *tile,
+                                          double *lds, int tid, const Lane &q) {
     if (GEN == 0) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -623,10 +597,9 @@ __global__ __launch_bounds__(THREADS, 2) void panel_kernel(Mats p, int j, int n_
             }
         return;
     }
-    // ---- fused Gram: A[r][c] = [scale *] (1/m) * #{t: leaf ids agree}  (+ jitter on the global diagonal) ----
     const int npad = p.nrb * NB;
-    uint32_t *rows_l = reinterpret_cast<uint32_t *>(lds);  // [W][128] ids of this tile's rows
-    uint32_t *cols_l = rows_l + p.nW * NB;                   // [W][128] ids of this tile's columns
+    uint32_t *rows_l = reinterpret_cast<uint32_t *>(lds);  // [W][128] codes of this tile's rows
+    uint32_t *cols_l = rows_l + p.nW * NB;                   // [W][128] codes of this tile's columns
     const uint32_t *lb = p.leafx + (size_t)b * p.nW * npad;
     for (int e = tid; e < p.nW * NB; e += THREADS) {
         const int w = e >> 7, r = e & (NB - 1);
@@ -641,7 +614,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_kernel(Mats p, int j, int n_
     const double jitter = 1e-6 + p.noise[b];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-        uint32_t miss[4][4] = {};
+        uint32_t cnt[4][4] = {};
         for (int w = 0; w < p.nW; ++w) {
             uint32_t cw[4], rw[4];
 #pragma unroll
@@ -651,7 +624,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_kernel(Mats p, int j, int n_
 #pragma unroll
             for (int v = 0; v < 4; ++v)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) miss[v][nt] += code_count<(GEN > 0 ? GEN - 1 : 0)>(rw[v], cw[nt]);
+                for (int nt = 0; nt < 4; ++nt) cnt[v][nt] += code_count<(GEN > 0 ? GEN - 1 : 0)>(rw[v], cw[nt]);
         }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -662,7 +635,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_kernel(Mats p, int j, int n_
                 const int cc = acc_col(q, nt), gj = cb * NB + cc;
                 double val;
                 if (gi < p.N && gj < p.N) {
-                    val = inv_m * (double)agree_count<(GEN > 0 ? GEN - 1 : 0)>(miss[v][nt], p.m);
+                    val = inv_m * (double)agree_count<(GEN > 0 ? GEN - 1 : 0)>(cnt[v][nt], p.m);
                     if (has_shift) val = val - sh;
                     if (has_scale) val = sc * val;
                     if (gi == gj) val = val + jitter;
@@ -673,6 +646,53 @@ __global__ __launch_bounds__(THREADS, 2) void panel_kernel(Mats p, int j, int n_
             }
         }
     }
+}
+
+// y_i -= U[j,i]' z_j in a fixed summation order: per 16-row tile rt, p[rt][c] = sum of the lane's four rows (fma chain), then over the four lane groups
+// (xor 16, xor 32); then y[c] -= ((p[0][c] + p[1][c]) + ...) + p[7][c].  `o` = the wave's U values of row tile rt,
+// columns col0 + nt*16 + lr; z = z_j; part = LDS [8][128].
+__device__ __forceinline__ void y_partial(const f64x4 (&o)[4], int rt, const double *__restrict__ z, double *part, int col0,
+                                          const Lane &q) {
+    double zr[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) zr[v] = z[rt * 16 + q.lk + 4 * v];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        double s = 0.0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) s = fma(o[nt][v], zr[v], s);
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (q.lk == 0) part[rt * NB + col0 + nt * 16 + q.lr] = s;
+    }
+}
+__device__ __forceinline__ void y_commit(const double *part, double *yi, int tid) {  // after a barrier; tid < 128
+    double s = part[tid];
+#pragma unroll
+    for (int rt = 1; rt < NSB_ROWS; ++rt) s += part[rt * NB + tid];
+    yi[tid] = yi[tid] - s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// row_kernel: T[j,i] = A[j,i] - sum_{k<j} U[k,j]' U[k,i]  for every column block i > j, and the partial diagonal
+// tile P[j+1,j+1] (same sum; diag_kernel(j+1) adds the k = j term).  1-D grid, (matrix, tile) from xcd_map.
+// Fusing the triangular solve into this kernel's epilogue was built twice this round (T kept in registers; T read
+// back through L2 by the same workgroup) and rejected on measurements: DESIGN.md, "Fused solve".
+// ---------------------------------------------------------------------------------------------
+template <int GEN>  // 0: A tile read from HBM; 1 + LeafRep: A generated from the leaf codes (bytes8 / bytes7 / bits)
+__global__ __launch_bounds__(THREADS, 2) void row_kernel(Mats p, int j, int n_right, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x;
+    int b, t;
+    if (!xcd_map(blockIdx.x, n_tiles, p.Bc, b, t)) return;
+    const Lane q = lane_of(tid);
+    double *Ab = p.A + (size_t)b * p.bstride;
+    const int rb = t < n_right ? j : j + 1;
+    const int cb = t < n_right ? j + 1 + t : j + 1;
+    f64x4 acc[4][4];
+    zero_acc(acc);
+    gemm_kmajor_dma(acc, Ab + (size_t)rb * NB, p.ld, Ab + (size_t)cb * NB, p.ld, j * NB, lds, tid, q);
+    form_tile<GEN>(acc, p, b, rb, cb, Ab + (size_t)rb * NB * p.ld + (size_t)cb * NB, lds, tid, q);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -757,32 +777,13 @@ __global__ __launch_bounds__(THREADS, 2) void solve_kernel(Mats p, int j, int n_
         }
     if (cb >= p.nrb) return;  // candidate columns: no right-hand-side update
 
-    // y_i[c] -= sum_r U[j,i][r][c] * z_j[r]
-    double *zs = lds;            // [128]
-    double *part = lds + NB;     // [2][128]
+    // y_i[c] -= sum_r U[j,i][r][c] * z_j[r]   (summation order: y_partial / y_commit)
+    double *part = lds;  // [8][128]; the GEMM ended with a barrier
     const double *zb = p.yz + (size_t)b * p.nrb * NB + (size_t)j * NB;
-    if (tid < NB) zs[tid] = zb[tid];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) y_partial(acc[mt], rt[mt], zb, part, q.wc * 64, q);
     __syncthreads();
-    double s[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const double z = zs[rt[mt] * 16 + q.lk + 4 * v];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) s[nt] = fma(acc[mt][nt][v], z, s[nt]);
-        }
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        s[nt] += __shfl_xor(s[nt], 16);
-        s[nt] += __shfl_xor(s[nt], 32);
-        if (q.lk == 0) part[q.wr * NB + acc_col(q, nt)] = s[nt];
-    }
-    __syncthreads();
-    if (tid < NB) {
-        double *yi = p.yz + (size_t)b * p.nrb * NB + (size_t)cb * NB;
-        yi[tid] = yi[tid] - (part[tid] + part[NB + tid]);
-    }
+    if (tid < NB) y_commit(part, p.yz + (size_t)b * p.nrb * NB + (size_t)cb * NB, tid);
 }
 
 // right-hand-side block := identity (N x N inside the padded candidate columns)
@@ -990,21 +991,10 @@ constexpr size_t DIAG_LDS = (size_t)(NBLK * SB * SB + 4 * SB * TS + 2 * NB + 8) 
 constexpr size_t GEMM_LDS = (size_t)GEMM_LDS_DOUBLES * sizeof(double);
 static_assert(DIAG_LDS >= GEMM_LDS, "diag kernel reuses its LDS for the K=128 GEMM stage");
 
-// tuning aid: BARK_DEBUG_PANEL_LDS=<bytes> pads the panel kernel's LDS request (forces 1 workgroup per CU)
-size_t debug_extra_lds() {
-    static long v = -1;
-    if (v < 0) {
-        const char *e = getenv("BARK_DEBUG_PANEL_LDS");
-        v = e ? atol(e) : 0;
-    }
-    return (size_t)v;
-}
-
-// diag(j) and panel(j) both depend only on solve(j-1), so they run concurrently (speed only; every
-// kernel's inputs are ordered by events): diag stays on the caller's stream (it is dispatched the moment
-// solve(j-1) retires and claims one slot per CU; its 82 KiB of LDS leave room for a panel workgroup beside
-// it) and the panel kernel is forked onto a helper stream and joined before solve(j).  The helper stream
-// and the events are created once per device and reused; the pattern is fork/join, so it is capturable.
+// The diag kernel runs concurrently with row launches (Sweep::step; speed only, every kernel's inputs are ordered by
+// events): diag stays on the caller's stream (its 82 KiB of LDS leave room for a row workgroup beside it on a CU) and
+// the bulk row launches go to a helper stream.  The helper stream and the events are created once and reused; the
+// pattern is fork/join, so it is capturable.
 // (Tried and rejected: splitting the resident matrices into two independently advancing lanes so that
 // one lane's panel kernel covers the other's diag/solve phases — 5 % slower at B = 256, 4 % at B = 64.)
 struct DeviceRes {
@@ -1041,14 +1031,14 @@ int set_lds_limits() {
     if (done[dev]) return BARK_OK;
     BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(diag_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)DIAG_LDS));
-    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(panel_kernel<0>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS + debug_extra_lds())));
-    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(panel_kernel<1>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS + debug_extra_lds())));
-    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(panel_kernel<2>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS + debug_extra_lds())));
-    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(panel_kernel<3>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GEMM_LDS + debug_extra_lds())));
+    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(row_kernel<0>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
+    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(row_kernel<1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
+    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(row_kernel<2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
+    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(row_kernel<3>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
     BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(panel_split_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
     BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(vtv_kernel),
@@ -1087,57 +1077,81 @@ struct Sweep {
         return BARK_OK;
     }
 
-    // block column j of the current chunk (p.Bc matrices): diag || panel, then solve
+    int launch_rows(hipStream_t st, int j, int n_right, int n_tiles) {
+        const dim3 g(xcd_grid(n_tiles, p.Bc)), blk(THREADS);
+        if (!fused)
+            hipLaunchKernelGGL(row_kernel<0>, g, blk, GEMM_LDS, st, p, j, n_right, n_tiles);
+        else if (rep == REP_BITS)
+            hipLaunchKernelGGL(row_kernel<1 + REP_BITS>, g, blk, GEMM_LDS, st, p, j, n_right, n_tiles);
+        else if (rep == REP_BYTES7)
+            hipLaunchKernelGGL(row_kernel<1 + REP_BYTES7>, g, blk, GEMM_LDS, st, p, j, n_right, n_tiles);
+        else
+            hipLaunchKernelGGL(row_kernel<1 + REP_BYTES8>, g, blk, GEMM_LDS, st, p, j, n_right, n_tiles);
+        BARK_LAUNCH_CHECK();
+        return BARK_OK;
+    }
+
+    int launch_diag(int j) {
+        int r;
+        if (timed) diag_marks.push_back(ev.size());
+        if ((r = mark_on(main))) return r;
+        hipLaunchKernelGGL(diag_kernel, dim3((unsigned)p.Bc), dim3(THREADS), DIAG_LDS, main, p, j);
+        BARK_LAUNCH_CHECK();
+        return mark_on(main);
+    }
+
+    // everything enqueued on `main` so far precedes what follows on the panel stream
+    int fork(int slot) {
+        if (panel == main) return BARK_OK;
+        BARK_HIP_CHECK(hipEventRecord(res->events[slot], main));
+        BARK_HIP_CHECK(hipStreamWaitEvent(panel, res->events[slot], 0));
+        return BARK_OK;
+    }
+    // everything enqueued on the panel stream so far precedes what follows on `main`
+    int join(int slot) {
+        if (panel == main) return BARK_OK;
+        BARK_HIP_CHECK(hipEventRecord(res->events[slot], panel));
+        BARK_HIP_CHECK(hipStreamWaitEvent(main, res->events[slot], 0));
+        return BARK_OK;
+    }
+
+    // Block column j of the current chunk (p.Bc matrices): diag(j) || rows(j), then solve(j).  diag(j) and rows(j)
+    // both depend only on solve(j-1): diag stays on the caller's stream (dispatched the moment solve(j-1) retires,
+    // one slot per CU, 82 KiB of LDS leave room for a row workgroup beside it), the rows go to the helper stream
+    // and are joined before solve(j).
     int step(int j) {
         hipStream_t s = main, ps = panel;
         const int bc = p.Bc;
         const int n_right = ncb - j - 1;
         const int n_diag = (j + 1 < nrb) ? 1 : 0;
-        const bool has_panel = j >= 1 && n_right + n_diag > 0;
-        const bool forked = ps != s;
+        const int n_tiles = n_right + n_diag;
         int r;
-        if (forked && has_panel) {  // fork: panel(j) waits for everything enqueued so far (solve(j-1))
-            BARK_HIP_CHECK(hipEventRecord(res->events[2 * j], s));
-            BARK_HIP_CHECK(hipStreamWaitEvent(ps, res->events[2 * j], 0));
+        int S = 1;  // split-K factor: fill ~SPLITK_SLOTS workgroup slots, >= 1 block row per slab
+        if (splitk && j >= 1 && n_tiles > 0 && n_tiles * bc < SPLITK_SLOTS / 2) {
+            S = SPLITK_SLOTS / (n_tiles * bc);
+            if (S > j) S = j;
+            if (S > SPLITK_MAX) S = SPLITK_MAX;
         }
-        if (timed) diag_marks.push_back(ev.size());
-        if ((r = mark_on(s))) return r;
-        hipLaunchKernelGGL(diag_kernel, dim3((unsigned)bc), dim3(THREADS), DIAG_LDS, s, p, j);
-        BARK_LAUNCH_CHECK();
-        if ((r = mark_on(s))) return r;
-        if (has_panel) {
+        // j == 0: with a materialised A the tiles T = A are in place; in fused-Gram sweeps the K = 0 launch writes them
+        const bool has_rows = (j >= 1 || fused) && n_tiles > 0;
+        if (has_rows && (r = fork(2 * j))) return r;  // rows(j) wait for everything enqueued so far (solve(j-1))
+        if ((r = launch_diag(j))) return r;
+        if (has_rows) {
             if (timed) panel_marks.push_back(ev.size());
             if ((r = mark_on(ps))) return r;
-            const int n_tiles = n_right + n_diag;
-            const dim3 pg(xcd_grid(n_tiles, bc));
-            const size_t pl = GEMM_LDS + debug_extra_lds();
-            int S = 1;  // split-K factor: fill ~SPLITK_SLOTS workgroup slots, >= 1 block row per slab
-            if (splitk && n_tiles * bc < SPLITK_SLOTS / 2) {
-                S = SPLITK_SLOTS / (n_tiles * bc);
-                if (S > j) S = j;
-                if (S > SPLITK_MAX) S = SPLITK_MAX;
-            }
             if (S > 1) {
                 hipLaunchKernelGGL(panel_split_kernel, dim3(xcd_grid(n_tiles * S, bc)), dim3(THREADS), GEMM_LDS, ps, p, j,
                                    n_right, n_tiles, S, slabs);
                 BARK_LAUNCH_CHECK();
                 hipLaunchKernelGGL(panel_reduce_kernel, dim3((unsigned)(n_tiles * (NB / RED_ROWS)), (unsigned)bc), dim3(THREADS),
                                    0, ps, p, j, n_right, n_tiles, S, slabs);
-            } else if (!fused)
-                hipLaunchKernelGGL(panel_kernel<0>, pg, dim3(THREADS), pl, ps, p, j, n_right, n_tiles);
-            else if (rep == REP_BITS)
-                hipLaunchKernelGGL(panel_kernel<1 + REP_BITS>, pg, dim3(THREADS), pl, ps, p, j, n_right, n_tiles);
-            else if (rep == REP_BYTES7)
-                hipLaunchKernelGGL(panel_kernel<1 + REP_BYTES7>, pg, dim3(THREADS), pl, ps, p, j, n_right, n_tiles);
-            else
-                hipLaunchKernelGGL(panel_kernel<1 + REP_BYTES8>, pg, dim3(THREADS), pl, ps, p, j, n_right, n_tiles);
-            BARK_LAUNCH_CHECK();
-            if ((r = mark_on(ps))) return r;
-            panel_flops += 2.0 * NB * NB * (double)(j * NB) * (double)(n_right + n_diag) * (double)bc;
-            if (forked) {  // join: solve(j) (and diag(j+1)) need the panel's tiles
-                BARK_HIP_CHECK(hipEventRecord(res->events[2 * j + 1], ps));
-                BARK_HIP_CHECK(hipStreamWaitEvent(s, res->events[2 * j + 1], 0));
+                BARK_LAUNCH_CHECK();
+            } else if ((r = launch_rows(ps, j, n_right, n_tiles))) {
+                return r;
             }
+            if ((r = mark_on(ps))) return r;
+            panel_flops += 2.0 * NB * NB * (double)(j * NB) * (double)n_tiles * (double)bc;
+            if ((r = join(2 * j + 1))) return r;  // solve(j) (and diag(j+1)) need the row's tiles
         }
         if (n_right > 0) {
             if (timed) solve_marks.push_back(ev.size());
@@ -1230,17 +1244,14 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
     const int words = (int)bark_leaf_words(info);
     if (words > MAX_LEAF_WORDS) return fail(BARK_ERR_ARG, "forest needs %d leaf-code words per point (max %d)", words, MAX_LEAF_WORDS);
     const bool use_scale = (flags & BARK_MLL_INCLUDE_SCALE) != 0;
-    // MLL-only sweeps generate A inside the panel kernel; only block rows 0 and 1 are materialised
-    // (inputs of diag(0), solve(0), diag(1)).  With candidates the whole matrix is filled up front.
-    static const bool fuse_env = getenv("BARK_NO_FUSED_GRAM") == nullptr;
-    static const bool splitk_env = getenv("BARK_NO_SPLITK") == nullptr;
-    const bool splitk = L.splitk && splitk_env;  // then A is materialised (the reduce kernel reads it)
-    const bool fused = fuse_env && !splitk && C == 0 && (size_t)2 * words * NB * sizeof(uint32_t) <= GEMM_LDS;
+    // MLL-only sweeps generate A inside the row kernels; only the tile (0, 0) is materialised (input of diag(0)).
+    // With candidates (or split-K) the whole matrix is filled up front.
+    const bool splitk = L.splitk;  // then A is materialised (the reduce kernel reads it)
+    const bool fused = !splitk && C == 0 && (size_t)2 * words * NB * sizeof(uint32_t) <= GEMM_LDS;
     double *slabs = reinterpret_cast<double *>(static_cast<char *>(workspace) + L.off_slab);
-    static const bool overlap_env = getenv("BARK_NO_DIAG_OVERLAP") == nullptr;
     const int nrb = (int)(L.npad / NB), ncb = (int)(L.ncols / NB);
     DeviceRes *res = nullptr;
-    if (overlap_env && (rc = get_device_res(&res, (size_t)2 * nrb))) return rc;
+    if ((rc = get_device_res(&res, (size_t)2 * nrb))) return rc;
 
     Sweep sw;
     sw.res = res;
@@ -1288,8 +1299,8 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
         if (sw.timed) sw.gram_marks.push_back(sw.ev.size());
         if ((r = sw.mark_on(s))) return r;
         if ((r = bark_leaf_codes_hip(packed_c, &sub, X, N, d, leafx, s))) return r;
-        const int fill_rows = fused ? (int)(L.npad < 2 * NB ? L.npad : 2 * NB) : (int)L.npad;
-        r = launch_gram(leafx, (int)L.npad, leafx, (int)L.npad, bc, m, (int)N, (int)N, fill_rows, (int)L.npad,
+        const int fill = fused ? NB : (int)L.npad;
+        r = launch_gram(leafx, (int)L.npad, leafx, (int)L.npad, bc, m, (int)N, (int)N, fill, fill,
                         p.shift, p.scale, p.noise, p.A, L.ld, p.bstride, true, true, rep, words, s);
         if (r) return r;
         if (rhs_identity) {
@@ -1425,10 +1436,9 @@ static int leafspace_run(const void *packed, const bark_pack_info *info, const d
     int rc = set_lds_limits();
     if (rc) return rc;
     hipStream_t caller = static_cast<hipStream_t>(stream_);
-    static const bool overlap_env = getenv("BARK_NO_DIAG_OVERLAP") == nullptr;
     const int nrb = (int)(g.Rpad / NB);
     DeviceRes *res = nullptr;
-    if (overlap_env && (rc = get_device_res(&res, (size_t)2 * nrb))) return rc;
+    if ((rc = get_device_res(&res, (size_t)2 * nrb))) return rc;
 
     char *ws = static_cast<char *>(workspace);
     const int ncb = (int)(g.L.ncols / NB);  // posterior: R identity columns appended (M^-1 and w = M^-1 v)

@@ -19,10 +19,6 @@
 // (tree_gps.py:97-100).  The library is built with -ffp-contract=off so no FMA fuses them.
 #include "common.h"
 
-#ifndef BARK_GRAM_ABLATE
-#define BARK_GRAM_ABLATE 0
-#endif
-
 namespace bark {
 namespace {
 
@@ -67,11 +63,7 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(GramArgs p) {
     const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, cx = lane & 31;
     const int rloc = wave * 16 + half * 8;
     uint32_t cnt[8][2] = {};  // disagreeing trees (byte codes) / agreeing trees (bit code)
-#if BARK_GRAM_ABLATE == 1  // timing only: no compare loop
-    for (int w = 0; w < 0; ++w) {
-#else
     for (int w = 0; w < p.W; ++w) {
-#endif
         const uint4 ra = *reinterpret_cast<const uint4 *>(rows + w * GT + rloc);
         const uint4 rb = *reinterpret_cast<const uint4 *>(rows + w * GT + rloc + 4);
         const uint2 cc = *reinterpret_cast<const uint2 *>(cols + w * GT + 2 * cx);
@@ -111,9 +103,6 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(GramArgs p) {
             v[q] = val;
         }
         double *dst = outb + (size_t)i * p.ld + j0;
-#if BARK_GRAM_ABLATE == 2  // timing only: (almost) no stores
-        if (v[0] != -1.0) continue;
-#endif
         if (VEC2 && j0 + 1 < p.Mout) {
             *reinterpret_cast<double2 *>(dst) = make_double2(v[0], v[1]);
         } else {

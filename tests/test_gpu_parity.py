@@ -588,6 +588,36 @@ def test_single_large_matrix_split_k_path(B):
     assert np.array_equal(again, first)
 
 
+def test_many_small_matrices_and_chunk_invariance(B):
+    """B = 288 forests at N = 700 (6 block rows): a filled chip of small matrices against the oracle's LU route, and
+    the same forests factorised 64 at a time: without split-K a forest's result does not depend on the chunk it
+    sits in (identical bits).  Also with candidates (materialised A, candidate columns carry no right-hand side)."""
+    nb, N = 288, 700
+    X, y, bounds, ft = B.syn.mixed_problem(N, seed=31)
+    F = B.syn.sample_prior_forests(nb, 50, bounds, ft, seed=310)
+    rng = np.random.default_rng(31)
+    noise, scale = rng.uniform(0.05, 0.2, nb), rng.uniform(0.7, 1.4, nb)
+    sub = np.r_[0:24, nb - 8:nb]  # the oracle on a sample; the rest through chunk invariance below
+    want = B.orc.batched_mll(F[sub], noise[sub], scale[sub], X, y, ft, include_scale=True, include_2pi=True)
+    fused = B.fit.batched_mll(F, noise, scale, X, y, ft, include_scale=True, include_2pi=True)
+    assert np.allclose(fused[sub], want, rtol=MLL_RTOL, atol=MLL_ATOL), np.abs(fused[sub] - want).max()
+    small = B.fit.batched_mll(F, noise, scale, X, y, ft, include_scale=True, include_2pi=True, chunk=64)
+    assert np.array_equal(fused, small)
+    # ragged last chunk, other convention
+    part = B.fit.batched_mll(F, noise, None, X, y, ft, include_scale=False, include_2pi=True, chunk=200)
+    want2 = B.orc.batched_mll(F[sub], noise[sub], None, X, y, ft, include_scale=False, include_2pi=True)
+    assert np.allclose(part[sub], want2, rtol=MLL_RTOL, atol=MLL_ATOL)
+    # posterior: 200 candidates appended as extra block columns
+    cand, _, _, _ = B.syn.mixed_problem(200, seed=32)
+    mu, var = B.tk.forest_predict((F, noise, scale), (X, y), cand, ft)
+    mu0, var0 = B.orc.forest_predict((F[:24], noise[:24], scale[:24]), (X, y), cand, ft)
+    assert np.allclose(mu[:24], mu0, rtol=1e-9, atol=1e-9) and np.allclose(var[:24], var0, rtol=1e-9, atol=1e-9)
+    from bark_amd.fitting.mll import _run
+    import bark_amd._lib as L
+    _, mu8, var8 = _run(F, noise, scale, X, y, ft, L.MLL_INCLUDE_SCALE, cand=cand, chunk=64)
+    assert np.array_equal(mu8.cpu().numpy(), mu) and np.array_equal(var8.cpu().numpy(), var)
+
+
 def test_leafspace_mll_equals_dense_and_reference(B):
     """method="leafspace" (R x R system over the leaves) against the golden MLLs, the oracle and the dense path."""
     for name in ("g3_prior_mixed_n257", "g8_batched_mll", "g10_mcmc_posterior_forests", "g4_all_null"):
