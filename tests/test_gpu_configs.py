@@ -1,0 +1,158 @@
+"""BASELINE.json configs c1, c2, c4 and c5 at their stated sizes (c3: test_gpu_parity.py::test_c3_full_size_properties
+and the bench's in-run check).  Inputs follow SURVEY §8d; the checker is the CPU oracle (LU route = the reference's
+arithmetic) where it finishes in seconds and a CPU Cholesky for the one N = 16384 matrix of c5."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MLL_RTOL, MLL_ATOL = 1e-9, 1e-8
+
+
+def test_c1_tree_function_n64():
+    """configs[0]: TreeFunction benchmark (dim 5, 50 trees, function_seed 1), N = 64, one prior forest."""
+    import bark_amd.fitting as fit
+    from bark_amd import synthetic as syn
+    from oracle import oracle as orc
+
+    _forest, _leaf_values, f = syn.tree_function()
+    X = np.random.default_rng(64).uniform(size=(64, 5))
+    y = f(X).reshape(-1, 1)
+    y = (y - y.mean()) / y.std()
+    ft = np.full(5, 2)
+    prior = syn.sample_prior_forests(1, 50, np.tile([[0.0, 1.0]], (5, 1)), ft, seed=64)
+    for conv in (dict(include_scale=True, include_2pi=False), dict(include_scale=False, include_2pi=True)):
+        got = fit.batched_mll(prior, [0.1], [1.0], X, y, ft, **conv)
+        want = orc.batched_mll(prior, [0.1], [1.0], X, y, ft, **conv)
+        assert np.allclose(got, want, rtol=MLL_RTOL, atol=MLL_ATOL)
+
+
+def test_c2_n1024_single_forest():
+    """configs[1]: N = 1024, d = 8, 50 trees, one forest: leaves and Gram bit-exact, MLL within tolerance."""
+    import bark_amd.fitting as fit
+    import bark_amd.forest as bf
+    from bark_amd import synthetic as syn
+    from oracle import oracle as orc
+
+    X, y, bounds, ft = syn.unit_cube_problem(1024, 8, seed=1024)
+    F = syn.sample_prior_forests(1, 50, bounds, ft, seed=1024)
+    assert np.array_equal(bf.pass_through_forest(F[0], X, ft), orc.pass_through_forest(F[0], X, ft))
+    assert np.array_equal(bf.forest_gram_matrix(F[0], X, X, ft), orc.forest_gram_matrix(F[0], X, X, ft))
+    got = fit.batched_mll(F, [0.1], [1.0], X, y, ft, include_scale=True, include_2pi=True)
+    want = orc.batched_mll(F, [0.1], [1.0], X, y, ft, include_scale=True, include_2pi=True)
+    assert np.allclose(got, want, rtol=MLL_RTOL, atol=MLL_ATOL), (got, want)
+
+
+def test_c5_n16384_mixed_posterior_10k_candidates():
+    """configs[4]: N = 16384 mixed categorical + integer + continuous, fp64 blocked Cholesky (split-K rows, 128 block
+    rows) + posterior predictive at 10^4 candidates, one forest.  Checker: CPU Cholesky of the oracle's Gram matrix
+    (the LU inverse of a 16384^2 matrix takes minutes), plus the leaf-space closed form of the same posterior."""
+    import scipy.linalg as sla
+    import torch
+
+    import bark_amd.fitting as fit
+    import bark_amd.forest as bf
+    import bark_amd.tree_kernels as tk
+    from bark_amd import synthetic as syn
+    from oracle import oracle as orc
+
+    N, C = 16384, 10000
+    X, y, bounds, ft = syn.mixed_problem(N, seed=16384)
+    cand, _, _, _ = syn.mixed_problem(C, seed=16385)
+    F = syn.sample_prior_forests(1, 50, bounds, ft, seed=16384)
+    noise, scale = np.array([0.1]), np.array([1.0])
+    leaves = bf.pass_through_forest(F[0], X, ft)
+    assert np.array_equal(leaves, orc.pass_through_forest(F[0], X, ft))  # 16384 x 50 leaf indices, bit-exact
+    Xd, cd = torch.from_numpy(X).cuda(), torch.from_numpy(cand).cuda()
+    mu, var = tk.forest_predict((F, noise, scale), (Xd, y), cd, ft)
+    mll = fit.batched_mll(F, noise, scale, Xd, y, ft, include_scale=True, include_2pi=False)
+    mu, var = mu.cpu().numpy(), var.cpu().numpy()
+    # oracle: Gram matrices from the C restatement, Cholesky route on the host
+    K = orc.forest_gram_matrix(F[0], X, X, ft)
+    Kg = bf.forest_gram_matrix(F[0], Xd, Xd, ft)
+    assert np.array_equal(Kg.cpu().numpy(), K)  # 2.1 GB of Gram entries, bit-exact
+    del Kg
+    K *= scale[0]
+    K[np.diag_indices(N)] += 1e-6 + noise[0]
+    Kx = scale[0] * orc.forest_gram_matrix(F[0], cand, X, ft)
+    c = sla.cholesky(K, lower=True, check_finite=False, overwrite_a=True)
+    z = sla.solve_triangular(c, y, lower=True, check_finite=False)
+    V = sla.solve_triangular(c, Kx.T, lower=True, check_finite=False)
+    mu0, var0 = (V.T @ z).ravel(), scale[0] - (V * V).sum(0)
+    mll0 = 0.5 * (-(z.T @ z)[0, 0] - 2.0 * np.log(np.diag(c)).sum())
+    assert abs(mll[0] - mll0) <= MLL_ATOL + MLL_RTOL * abs(mll0), (mll[0], mll0)
+    assert np.allclose(mu[0], mu0, rtol=1e-9, atol=1e-9), np.abs(mu[0] - mu0).max()
+    assert np.allclose(var[0], var0, rtol=1e-9, atol=1e-9), np.abs(var[0] - var0).max()
+    assert var.min() > 0.0
+    # leaf-space closed form of the same posterior (no N x N matrix at all)
+    mu_l, var_l = tk.forest_predict((F, noise, scale), (Xd, y), cd, ft, method="leafspace")
+    assert np.allclose(mu_l.cpu().numpy(), mu, rtol=1e-8, atol=1e-9) and np.allclose(var_l.cpu().numpy(), var, rtol=1e-8, atol=1e-9)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _c4_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import bark_amd.fitting as fit
+    from bark_amd import synthetic
+    from bark_amd.distributed import gather_mll, shard_range
+
+    total, N = 512, 4096
+    X, y, bounds, ft = synthetic.unit_cube_problem(N, 8, seed=N)
+    lo, hi = shard_range(total, rank, world)
+    F = synthetic.sample_prior_forests(hi - lo, 50, bounds, ft, seed=N + lo)  # forest b is seeded by its global index
+    noise = np.random.default_rng(7).uniform(0.05, 0.15, total)[lo:hi]
+    local = fit.batched_mll(F, noise, None, X, y, ft, include_scale=False, include_2pi=True, return_device=True)
+    full = gather_mll(local.cpu(), total)
+    q.put((rank, full.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_c4_512_samples_sharded_equal_unsharded():
+    """configs[3]: N = 4096, 512 forest samples in contiguous shards (forest.py:92-98 loop order).  Here 4 ranks of
+    128 share the one GPU of the test box (gloo gathers host copies; on a node each rank has its own GPU and RCCL
+    gathers device tensors): every rank ends with the same (512,) vector, equal bit for bit to one unsharded call,
+    and a sample of it agrees with the oracle."""
+    import torch.multiprocessing as mp
+
+    import bark_amd.fitting as fit
+    from bark_amd import synthetic
+    from oracle import oracle as orc
+
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_c4_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=900) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in range(1, world):
+        assert np.array_equal(results[0], results[r])
+    total, N = 512, 4096
+    X, y, bounds, ft = synthetic.unit_cube_problem(N, 8, seed=N)
+    noise = np.random.default_rng(7).uniform(0.05, 0.15, total)
+    pick = [0, 1, 127, 128, 255, 256, 383, 511]  # shard edges (8 forests: enough resident matrices for the non-split-K path)
+    F = np.stack([synthetic.sample_prior_forests(1, 50, bounds, ft, seed=N + b)[0] for b in pick])
+    one = fit.batched_mll(F, noise[pick], None, X, y, ft, include_scale=False, include_2pi=True)
+    assert np.array_equal(results[0][pick], one)  # a forest's bits do not depend on the shard or chunk it sits in
+    want = orc.batched_mll(F[:1], noise[pick][:1], None, X, y, ft, include_scale=False, include_2pi=True)
+    assert np.allclose(one[:1], want, rtol=MLL_RTOL, atol=MLL_ATOL)
+    assert np.isfinite(results[0]).all()
