@@ -47,21 +47,34 @@ SIGNATURES = {
     "bark_last_error": (ctypes.c_char_p, []),
     "bark_forest_pack_info": (ci, [vp, i64, i64, i64, vp, i64, ctypes.POINTER(PackInfo)]),
     "bark_forest_pack": (ci, [vp, vp, i64, ctypes.POINTER(PackInfo), vp]),
-    "bark_leaf_indices_hip": (ci, [vp, ctypes.POINTER(PackInfo), vp, i64, i64, vp, vp]),
+    "bark_ctx_create": (ci, [ci, ctypes.POINTER(vp)]),
+    "bark_ctx_destroy": (None, [vp]),
+    "bark_ctx_workspace": (ci, [vp, ctypes.c_size_t, ctypes.POINTER(vp)]),
+    "bark_ctx_workspace_bytes": (ctypes.c_size_t, [vp]),
+    "bark_ctx_status": (ci, [vp, vp, ctypes.POINTER(ctypes.c_int32)]),
+    "bark_leaf_indices_hip": (ci, [vp, vp, ctypes.POINTER(PackInfo), vp, i64, i64, vp, vp]),
+    "bark_onehot_match_hip": (ci, [vp, i64, i64, vp, i64, ctypes.c_double, vp, i64, vp]),
+    "bark_rowdot_hip": (ci, [vp, i64, i64, i64, vp, ctypes.c_double, vp, ctypes.c_double, vp, vp]),
+    "bark_mixture_partial_hip": (ci, [vp, vp, i64, i64, vp, vp]),
+    "bark_mixture_finish_hip": (ci, [vp, ctypes.c_double, i64, vp, vp, vp]),
+    "bark_copy2d_hip": (ci, [vp, i64, vp, i64, i64, i64, vp]),
+    "bark_tree_sweep_chains_hip": (ci, [vp, vp, i64, i64, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp,
+                                        ctypes.c_size_t, vp]),
+    "bark_lowrank_status_hip": (ci, [vp, i64, i64, ctypes.POINTER(ctypes.c_int32), vp]),
     "bark_leaf_npad": (i64, [i64]),
     "bark_leaf_encoding": (ci, [ctypes.POINTER(PackInfo)]),
     "bark_leaf_words": (i64, [ctypes.POINTER(PackInfo)]),
-    "bark_leaf_codes_hip": (ci, [vp, ctypes.POINTER(PackInfo), vp, i64, i64, vp, vp]),
+    "bark_leaf_codes_hip": (ci, [vp, vp, ctypes.POINTER(PackInfo), vp, i64, i64, vp, vp]),
     "bark_gram_from_leaves_hip": (ci, [vp, i64, vp, i64, ctypes.POINTER(PackInfo), vp, vp, vp, vp, i64, i64, vp]),
     "bark_mll_workspace_bytes": (ctypes.c_size_t, [i64, i64, i64, i64]),
-    "bark_mll_batched_hip": (ci, [vp, ctypes.POINTER(PackInfo), vp, i64, i64, vp, vp, vp, vp, ci, vp, i64, vp, vp, vp,
+    "bark_mll_batched_hip": (ci, [vp, vp, ctypes.POINTER(PackInfo), vp, i64, i64, vp, vp, vp, vp, ci, vp, i64, vp, vp, vp,
                                   vp, vp, vp, ctypes.c_size_t, i64, ctypes.POINTER(MllTiming), vp]),
     "bark_quadform_hip": (ci, [vp, vp, i64, vp, vp]),
     "bark_mll_leafspace_workspace_bytes": (ctypes.c_size_t, [i64, i64, i64, i64, i64]),
-    "bark_mll_leafspace_hip": (ci, [vp, ctypes.POINTER(PackInfo), vp, i64, i64, vp, vp, vp, ci, vp, i64, vp, vp, vp, vp,
+    "bark_mll_leafspace_hip": (ci, [vp, vp, ctypes.POINTER(PackInfo), vp, i64, i64, vp, vp, vp, ci, vp, i64, vp, vp, vp, vp,
                                     vp, ctypes.c_size_t, i64, vp]),
     "bark_kernel_inverse_leafspace_workspace_bytes": (ctypes.c_size_t, [i64, i64, i64, i64]),
-    "bark_kernel_inverse_leafspace_hip": (ci, [vp, ctypes.POINTER(PackInfo), vp, i64, i64, vp, vp, vp, ci, vp, vp, vp, vp,
+    "bark_kernel_inverse_leafspace_hip": (ci, [vp, vp, ctypes.POINTER(PackInfo), vp, i64, i64, vp, vp, vp, ci, vp, vp, vp, vp,
                                                vp, ctypes.c_size_t, i64, vp]),
     "bark_lowrank_workspace_bytes": (ctypes.c_size_t, [i64, i64]),
     "bark_lowrank_update_hip": (ci, [vp, i64, vp, i64, ci, ci, vp, vp, vp, ctypes.c_size_t, vp]),
@@ -69,10 +82,10 @@ SIGNATURES = {
     "bark_lowrank_swap_apply_hip": (ci, [vp, i64, i64, vp, vp, vp]),
     "bark_tree_swap_workspace_bytes": (ctypes.c_size_t, [i64, i64]),
     "bark_tree_swap_chains_workspace_bytes": (ctypes.c_size_t, [i64, i64, i64, vp]),
-    "bark_tree_swap_eval_chains_hip": (ci, [vp, i64, i64, vp, ctypes.POINTER(PackInfo), vp, i64, vp, vp, vp, vp, vp,
+    "bark_tree_swap_eval_chains_hip": (ci, [vp, vp, i64, i64, vp, ctypes.POINTER(PackInfo), vp, i64, vp, vp, vp, vp, vp,
                                             ctypes.c_size_t, vp]),
     "bark_lowrank_swap_apply_chains_hip": (ci, [vp, i64, i64, i64, vp, vp, ctypes.c_size_t, vp]),
-    "bark_tree_swap_eval_hip": (ci, [vp, i64, vp, ctypes.POINTER(PackInfo), vp, i64, i64, ctypes.c_double, vp, vp, vp,
+    "bark_tree_swap_eval_hip": (ci, [vp, vp, i64, vp, ctypes.POINTER(PackInfo), vp, i64, i64, ctypes.c_double, vp, vp, vp,
                                      ctypes.c_size_t, vp]),
 }
 
@@ -152,21 +165,75 @@ def to_device(a, dtype=None):
     return t.to(dev, non_blocking=False)
 
 
-_workspace = None
+# ---- per-thread, per-device context (include/bark_hip.h bark_ctx): helper streams, events, scratch, fault flag ----
+_tls = threading.local()
 
 
-def workspace(nbytes: int):
-    """A cached, 256-byte aligned device scratch buffer that only grows."""
+def ctx():
+    """The calling thread's bark_ctx for the current device (created on first use).  Host threads never share a
+    context, so concurrent callers on their own streams share no mutable library state."""
     import torch
 
-    global _workspace
-    if _workspace is None or _workspace.numel() < nbytes or _workspace.device != torch_device():
-        _workspace = None  # release before growing
-        _workspace = torch.empty(int(nbytes), dtype=torch.uint8, device=torch_device())
-        assert _workspace.data_ptr() % 256 == 0
-    return _workspace
+    dev = torch_device().index
+    handles = getattr(_tls, "handles", None)
+    if handles is None:
+        handles = _tls.handles = {}
+    h = handles.get(dev)
+    if h is None:
+        h = vp()
+        check(lib().bark_ctx_create(dev, ctypes.byref(h)))
+        handles[dev] = h
+    return h
+
+
+def release_ctx():
+    """Destroy the calling thread's contexts (frees their scratch buffers); they are re-created on demand."""
+    import torch
+
+    handles = getattr(_tls, "handles", None) or {}
+    if handles and torch.cuda.is_available():
+        torch.cuda.synchronize()
+    for h in handles.values():
+        lib().bark_ctx_destroy(h)
+    handles.clear()
+    cache = getattr(_tls, "packed", None)
+    if cache is not None:
+        cache.clear()
+
+
+class Scratch:
+    """View of the context's grow-only device scratch (valid until a larger request or release_ctx)."""
+
+    def __init__(self, ptr_value: int, nbytes: int):
+        self._ptr, self._n = ptr_value, nbytes
+
+    def data_ptr(self) -> int:
+        return self._ptr
+
+    def numel(self) -> int:
+        return self._n
+
+
+def workspace(nbytes: int) -> Scratch:
+    out = vp()
+    check(lib().bark_ctx_workspace(ctx(), int(nbytes), ctypes.byref(out)))
+    assert out.value % 256 == 0
+    return Scratch(out.value, int(lib().bark_ctx_workspace_bytes(ctx())))
+
+
+def workspace_bytes() -> int:
+    handles = getattr(_tls, "handles", None) or {}
+    return sum(int(lib().bark_ctx_workspace_bytes(h)) for h in handles.values())
 
 
 def release_workspace():
-    global _workspace
-    _workspace = None
+    release_ctx()
+
+
+def check_categorical_fault():
+    """Raise what the reference raises inside `1 << int(x)` (forest.py:38) if a leaf walk enqueued by this thread met
+    a NaN / inf / negative value at a categorical split.  One 4-byte read-back (synchronises the current stream)."""
+    flag = ctypes.c_int32(0)
+    check(lib().bark_ctx_status(ctx(), stream_ptr(), ctypes.byref(flag)))
+    if flag.value:
+        raise ValueError("categorical feature value is negative, NaN or inf")

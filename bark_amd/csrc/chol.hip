@@ -36,6 +36,7 @@
 // As[k][128(+16 pad)] is read conflict-free by ds_read_b64 (row stride 1152 B == 128 mod 256).
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -43,7 +44,9 @@
 namespace bark {
 
 int walk_one_hot(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d, int words,
-                 uint32_t *out, hipStream_t stream);
+                 uint32_t *out, int32_t *fault, hipStream_t stream);
+int walk_codes(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d, uint32_t *out,
+               int32_t *fault, hipStream_t stream);
 int leafspace_prepare(const uint32_t *codes, int W, int npad, unsigned long long *planes, int R, int Rpad,
                       const double *noise, const double *scale, int m, int bc, double *A, long ld, long bstride,
                       const double *y, int N, double *yz, double *accum, int32_t *info, hipStream_t s);
@@ -841,10 +844,18 @@ __global__ void init_rhs_kernel(const double *__restrict__ y, int N, int npad, d
     }
 }
 
+// a leaf walk of this call met an invalid categorical value: every sample of the chunk reports it (info = -1)
+__global__ void fault_info_kernel(const int32_t *fault, int32_t *info, int Bc) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < Bc && *fault) info[b] = -1;
+}
+
 // quick_inverse.py:38 / mcmc_record_mll.py:73
-__global__ void finish_mll_kernel(const double *accum, int Bc, int N, int include_2pi, double *mll) {
+__global__ void finish_mll_kernel(const double *accum, int Bc, int N, int include_2pi, double *mll, const int32_t *fault,
+                                  int32_t *info) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= Bc) return;
+    if (*fault) info[b] = -1;
     double v = -accum[(size_t)b * 2] - accum[(size_t)b * 2 + 1];
     if (include_2pi) v = v - (double)N * log(2.0 * M_PI);
     mll[b] = 0.5 * v;
@@ -997,57 +1008,36 @@ static_assert(DIAG_LDS >= GEMM_LDS, "diag kernel reuses its LDS for the K=128 GE
 // pattern is fork/join, so it is capturable.
 // (Tried and rejected: splitting the resident matrices into two independently advancing lanes so that
 // one lane's panel kernel covers the other's diag/solve phases — 5 % slower at B = 256, 4 % at B = 64.)
-struct DeviceRes {
-    hipStream_t helper = nullptr;
-    std::vector<hipEvent_t> events;  // 2 per block column (fork, join)
-};
-
-int get_device_res(DeviceRes **out, size_t n_events) {
-    static thread_local DeviceRes per_device[32];
-    int dev = 0;
-    BARK_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 32) return fail(BARK_ERR_ARG, "device index %d out of range", dev);
-    DeviceRes &r = per_device[dev];
-    if (!r.helper) {
-        int lo = 0, hi = 0;
-        BARK_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        BARK_HIP_CHECK(hipStreamCreateWithPriority(&r.helper, hipStreamNonBlocking, lo));
-    }
-    while (r.events.size() < n_events) {
-        hipEvent_t e;
-        BARK_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        r.events.push_back(e);
-    }
-    *out = &r;
-    return BARK_OK;
-}
+}  // namespace
 
 int set_lds_limits() {
     // kernels using more than 64 KiB of dynamic LDS need the limit raised once per device
-    static bool done[32] = {};
+    static std::once_flag once[64];
+    static int status[64];
     int dev = 0;
     BARK_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 32) return fail(BARK_ERR_ARG, "device index %d out of range", dev);
-    if (done[dev]) return BARK_OK;
-    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(diag_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)DIAG_LDS));
-    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(row_kernel<0>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
-    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(row_kernel<1>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
-    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(row_kernel<2>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
-    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(row_kernel<3>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
-    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(panel_split_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
-    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(vtv_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
-    BARK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(solve_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
-    done[dev] = true;
+    if (dev < 0 || dev >= 64) return fail(BARK_ERR_ARG, "device index %d out of range", dev);
+    std::call_once(once[dev], [dev]() {
+        auto set = [](const void *fn, size_t bytes) {
+            return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        };
+        hipError_t e = set(reinterpret_cast<const void *>(diag_kernel), DIAG_LDS);
+        if (e == hipSuccess) e = set(reinterpret_cast<const void *>(row_kernel<0>), GEMM_LDS);
+        if (e == hipSuccess) e = set(reinterpret_cast<const void *>(row_kernel<1>), GEMM_LDS);
+        if (e == hipSuccess) e = set(reinterpret_cast<const void *>(row_kernel<2>), GEMM_LDS);
+        if (e == hipSuccess) e = set(reinterpret_cast<const void *>(row_kernel<3>), GEMM_LDS);
+        if (e == hipSuccess) e = set(reinterpret_cast<const void *>(panel_split_kernel), GEMM_LDS);
+        if (e == hipSuccess) e = set(reinterpret_cast<const void *>(vtv_kernel), GEMM_LDS);
+        if (e == hipSuccess) e = set(reinterpret_cast<const void *>(solve_kernel), GEMM_LDS);
+        status[dev] = (int)e;
+    });
+    if (status[dev] != 0)
+        return fail(BARK_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s",
+                    hipGetErrorString((hipError_t)status[dev]));
     return BARK_OK;
 }
+
+namespace {
 
 // ---------------------------------------------------------------------------------------------
 // Sweep: the factorisation of one chunk of resident matrices, shared by the dense MLL / posterior entry
@@ -1057,7 +1047,7 @@ int set_lds_limits() {
 struct Sweep {
     Mats p;
     hipStream_t main = nullptr, panel = nullptr;  // panel == main: no overlap
-    DeviceRes *res = nullptr;
+    bark_ctx *res = nullptr;
     int nrb = 0, ncb = 0;
     bool fused = false, splitk = false;
     int rep = 0;
@@ -1168,7 +1158,7 @@ struct Sweep {
     // fill *t from the recorded events (synchronises); [t_begin, t_end] bracket the whole call on `caller`
     int report(bark_mll_timing *t, size_t t_begin, size_t t_end, hipStream_t caller) {
         BARK_HIP_CHECK(hipStreamSynchronize(caller));
-        if (res) BARK_HIP_CHECK(hipStreamSynchronize(res->helper));
+        if (res && res->helper) BARK_HIP_CHECK(hipStreamSynchronize(res->helper));
         int r;
         auto span = [&](size_t a, size_t b_, float *acc) -> int {
             float ms = 0.f;
@@ -1210,12 +1200,14 @@ size_t bark_mll_workspace_bytes(int64_t N, int64_t C, int64_t m, int64_t Bc) {
     return make_layout(N, C, m, Bc).total;
 }
 
-int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
+int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
                          const double *y, const double *noise, const double *scale, const double *shift, int flags,
                          const double *cand, int64_t C, double *mll_out, double *mu_out, double *var_out,
                          double *cov_out, int32_t *info_out,
                          void *workspace, size_t workspace_bytes, int64_t Bc, bark_mll_timing *timing, void *stream_) {
     error_buffer()[0] = 0;
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
     if (!packed || !info || !X || !y || !noise || !mll_out || !info_out || !workspace)
         return fail(BARK_ERR_ARG, "bark_mll_batched_hip: null argument");
     const int64_t B = info->B, m = info->m;
@@ -1236,8 +1228,7 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
     if (workspace_bytes < L.total)
         return fail(BARK_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", workspace_bytes, L.total);
     if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(BARK_ERR_ARG, "workspace must be 256-byte aligned");
-    int rc = set_lds_limits();
-    if (rc) return rc;
+    if ((rc = set_lds_limits())) return rc;
 
     hipStream_t caller = static_cast<hipStream_t>(stream_);
     const int rep = (int)leaf_rep(info);
@@ -1250,11 +1241,10 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
     const bool fused = !splitk && C == 0 && (size_t)2 * words * NB * sizeof(uint32_t) <= GEMM_LDS;
     double *slabs = reinterpret_cast<double *>(static_cast<char *>(workspace) + L.off_slab);
     const int nrb = (int)(L.npad / NB), ncb = (int)(L.ncols / NB);
-    DeviceRes *res = nullptr;
-    if ((rc = get_device_res(&res, (size_t)2 * nrb))) return rc;
+    if ((rc = ctx_events(ctx, (size_t)2 * nrb))) return rc;
 
     Sweep sw;
-    sw.res = res;
+    sw.res = ctx;
     sw.nrb = nrb;
     sw.ncb = ncb;
     sw.fused = fused;
@@ -1263,7 +1253,7 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
     sw.slabs = slabs;
     sw.timed = timing != nullptr;
     sw.main = caller;
-    sw.panel = res ? res->helper : caller;
+    sw.panel = ctx->helper;
     uint32_t *leafx, *leafc;
     {
         char *ws = static_cast<char *>(workspace);
@@ -1298,7 +1288,7 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
         int r;
         if (sw.timed) sw.gram_marks.push_back(sw.ev.size());
         if ((r = sw.mark_on(s))) return r;
-        if ((r = bark_leaf_codes_hip(packed_c, &sub, X, N, d, leafx, s))) return r;
+        if ((r = walk_codes(packed_c, &sub, X, N, d, leafx, ctx->fault, s))) return r;
         const int fill = fused ? NB : (int)L.npad;
         r = launch_gram(leafx, (int)L.npad, leafx, (int)L.npad, bc, m, (int)N, (int)N, fill, fill,
                         p.shift, p.scale, p.noise, p.A, L.ld, p.bstride, true, true, rep, words, s);
@@ -1308,7 +1298,7 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
             hipLaunchKernelGGL(identity_rhs_kernel, g, dim3(256), 0, s, p, (int)N, (int)L.cpad);
             BARK_LAUNCH_CHECK();
         } else if (C > 0) {
-            if ((r = bark_leaf_codes_hip(packed_c, &sub, cand, C, d, leafc, s))) return r;
+            if ((r = walk_codes(packed_c, &sub, cand, C, d, leafc, ctx->fault, s))) return r;
             r = launch_gram(leafx, (int)L.npad, leafc, (int)L.cpad, bc, m, (int)N, (int)C, (int)L.npad,
                             (int)L.cpad, p.shift, scale + c0, nullptr, p.A + L.npad, L.ld, p.bstride, false, false, rep, words, s);
             if (r) return r;
@@ -1323,7 +1313,7 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, const d
         Mats &p = sw.p;
         hipStream_t s = sw.main;
         hipLaunchKernelGGL(finish_mll_kernel, dim3((unsigned)((bc + 255) / 256)), dim3(256), 0, s, p.accum, (int)bc, (int)N,
-                           (flags & BARK_MLL_INCLUDE_2PI) ? 1 : 0, mll_out + c0);
+                           (flags & BARK_MLL_INCLUDE_2PI) ? 1 : 0, mll_out + c0, ctx->fault, p.info);
         BARK_LAUNCH_CHECK();
         if (C > 0) {
             const int prc = launch_predict_reduce(p, (int)N, (int)C, (int)bc, rhs_identity ? nullptr : scale + c0,
@@ -1409,12 +1399,14 @@ size_t bark_mll_leafspace_workspace_bytes(int64_t N, int64_t max_bits, int64_t m
 }  // extern "C"
 
 // shared driver of the leaf-space entry points: MLL always; posterior when C > 0; explicit inverse when kinv_out
-static int leafspace_run(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
+static int leafspace_run(bark_ctx *ctx, const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
                          const double *y, const double *noise, const double *scale, int flags, const double *cand,
                          int64_t C, double *mll_out, double *mu_out, double *var_out, double *kinv_out,
                          double *kinv_y_out, int32_t *info_out, void *workspace, size_t workspace_bytes, int64_t Bc,
                          void *stream_) {
     error_buffer()[0] = 0;
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
     if (!packed || !info || !X || !y || !noise || !mll_out || !info_out || !workspace)
         return fail(BARK_ERR_ARG, "leaf-space entry: null argument");
     const int64_t B = info->B, m = info->m;
@@ -1433,24 +1425,22 @@ static int leafspace_run(const void *packed, const bark_pack_info *info, const d
     const LeafLayout g = make_leaf_layout(N, info->max_bits, m, Bc, C, kinv_out != nullptr);
     if (workspace_bytes < g.total) return fail(BARK_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", workspace_bytes, g.total);
     if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(BARK_ERR_ARG, "workspace must be 256-byte aligned");
-    int rc = set_lds_limits();
-    if (rc) return rc;
+    if ((rc = set_lds_limits())) return rc;
     hipStream_t caller = static_cast<hipStream_t>(stream_);
     const int nrb = (int)(g.Rpad / NB);
-    DeviceRes *res = nullptr;
-    if ((rc = get_device_res(&res, (size_t)2 * nrb))) return rc;
+    if ((rc = ctx_events(ctx, (size_t)2 * nrb))) return rc;
 
     char *ws = static_cast<char *>(workspace);
     const int ncb = (int)(g.L.ncols / NB);  // posterior: R identity columns appended (M^-1 and w = M^-1 v)
     Sweep sw;
-    sw.res = res;
+    sw.res = ctx;
     sw.nrb = nrb;
     sw.ncb = ncb;
     sw.fused = false;
     sw.splitk = g.L.splitk;
     sw.slabs = reinterpret_cast<double *>(ws + g.L.off_slab);
     sw.main = caller;
-    sw.panel = res ? res->helper : caller;
+    sw.panel = ctx->helper;
     Mats &p = sw.p;
     p.A = reinterpret_cast<double *>(ws + g.L.off_A);
     p.ld = g.L.ld;
@@ -1481,7 +1471,7 @@ static int leafspace_run(const void *packed, const bark_pack_info *info, const d
         const char *packed_c = static_cast<const char *>(packed) + (size_t)c0 * m * info->stride * 16;
         p.info = info_out + c0;
         p.Bc = (int)bc;
-        if ((rc = walk_one_hot(packed_c, &sub, X, N, d, (int)g.W, codes, caller))) return rc;
+        if ((rc = walk_one_hot(packed_c, &sub, X, N, d, (int)g.W, codes, ctx->fault, caller))) return rc;
         rc = leafspace_prepare(codes, (int)g.W, (int)g.npad, planes, (int)g.R, (int)g.Rpad, noise + c0,
                                use_scale ? scale + c0 : nullptr, (int)m, (int)bc, p.A, p.ld, p.bstride, y, (int)N, p.yz,
                                p.accum, p.info, caller);
@@ -1506,7 +1496,7 @@ static int leafspace_run(const void *packed, const bark_pack_info *info, const d
                                (const double *)nullptr, 1.0, 1, Minv);
             BARK_LAUNCH_CHECK();
             if (C > 0) {
-                if ((rc = walk_one_hot(packed_c, &sub, cand, C, d, (int)g.W, ccodes, caller))) return rc;
+                if ((rc = walk_one_hot(packed_c, &sub, cand, C, d, (int)g.W, ccodes, ctx->fault, caller))) return rc;
                 rc = leafspace_predict(ccodes, (int)g.W, (int)g.cpad, (int)C, wvec, Minv, R, noise + c0, scale + c0, (int)m,
                                        (int)bc, mu_out + (size_t)c0 * C, var_out + (size_t)c0 * C, caller);
                 if (rc) return rc;
@@ -1519,21 +1509,24 @@ static int leafspace_run(const void *packed, const bark_pack_info *info, const d
                 if (rc) return rc;
             }
         }
+        hipLaunchKernelGGL(fault_info_kernel, dim3((unsigned)((bc + 255) / 256)), dim3(256), 0, caller, ctx->fault, p.info,
+                           (int)bc);
+        BARK_LAUNCH_CHECK();
     }
     return BARK_OK;
 }
 
 extern "C" {
 
-int bark_mll_leafspace_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
+int bark_mll_leafspace_hip(bark_ctx *ctx, const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
                            const double *y, const double *noise, const double *scale, int flags, const double *cand,
                            int64_t C, double *mll_out, double *mu_out, double *var_out, int32_t *info_out,
                            void *workspace, size_t workspace_bytes, int64_t Bc, void *stream_) {
-    return leafspace_run(packed, info, X, N, d, y, noise, scale, flags, cand, C, mll_out, mu_out, var_out, nullptr, nullptr,
+    return leafspace_run(ctx, packed, info, X, N, d, y, noise, scale, flags, cand, C, mll_out, mu_out, var_out, nullptr, nullptr,
                          info_out, workspace, workspace_bytes, Bc, stream_);
 }
 
-int bark_kernel_inverse_leafspace_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
+int bark_kernel_inverse_leafspace_hip(bark_ctx *ctx, const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
                                       const double *y, const double *noise, const double *scale, int flags,
                                       double *mll_out, double *kinv_out, double *kinv_y_out, int32_t *info_out,
                                       void *workspace, size_t workspace_bytes, int64_t Bc, void *stream_) {
@@ -1541,8 +1534,30 @@ int bark_kernel_inverse_leafspace_hip(const void *packed, const bark_pack_info *
         error_buffer()[0] = 0;
         return fail(BARK_ERR_ARG, "bark_kernel_inverse_leafspace_hip: kinv_out is null");
     }
-    return leafspace_run(packed, info, X, N, d, y, noise, scale, flags, nullptr, 0, mll_out, nullptr, nullptr, kinv_out,
+    return leafspace_run(ctx, packed, info, X, N, d, y, noise, scale, flags, nullptr, 0, mll_out, nullptr, nullptr, kinv_out,
                          kinv_y_out, info_out, workspace, workspace_bytes, Bc, stream_);
+}
+
+// out[b] = alpha * sum_i A[b][i] * y[i] + beta * c[b]  (one wave per row; fixed order; c may be null)
+__global__ __launch_bounds__(64) void rowdot_kernel(const double *__restrict__ A, const double *__restrict__ y, int64_t N,
+                                                     int64_t lda, double alpha, const double *__restrict__ c, double beta,
+                                                     double *__restrict__ out) {
+    const double *row = A + (size_t)blockIdx.x * lda;
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < N; i += 64) s = fma(row[i], y[i], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (threadIdx.x == 0) out[blockIdx.x] = c ? alpha * s + beta * c[blockIdx.x] : alpha * s;
+}
+
+int bark_rowdot_hip(const double *A, int64_t B, int64_t N, int64_t lda, const double *y, double alpha, const double *c,
+                    double beta, double *out, void *stream_) {
+    error_buffer()[0] = 0;
+    if (!A || !y || !out || B < 1 || N < 1 || lda < N || B > (1 << 30)) return fail(BARK_ERR_ARG, "bark_rowdot_hip: bad argument");
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)B), dim3(64), 0, static_cast<hipStream_t>(stream_), A, y, N, lda, alpha, c,
+                       beta, out);
+    BARK_LAUNCH_CHECK();
+    return BARK_OK;
 }
 
 int bark_quadform_hip(const double *K_inv, const double *y, int64_t N, double *out, void *stream_) {

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <vector>
 
 #include "../../include/bark_hip.h"
 
@@ -23,6 +24,31 @@ int fail(int code, const char *fmt, ...);
     } while (0)
 
 #define BARK_LAUNCH_CHECK() BARK_HIP_CHECK(hipGetLastError())
+
+}  // namespace bark
+
+// Per-device context (include/bark_hip.h: bark_ctx_create / bark_ctx_destroy).  Everything an entry point needs
+// beyond its arguments lives here, so two host threads with a context (and a stream) each never share state.
+struct bark_ctx {
+    int device = 0;
+    hipStream_t helper = nullptr;             // dense sweep: row launches beside the diag kernel
+    std::vector<hipEvent_t> events;           // fork / join events of the sweep (grown on demand, reused)
+    std::vector<hipStream_t> chain_streams;   // multi-chain sampler step: one stream per chain (general shapes)
+    std::vector<hipEvent_t> chain_done;
+    hipEvent_t chain_fork = nullptr;
+    void *ws = nullptr;                       // bark_ctx_workspace: grow-only device scratch
+    size_t ws_bytes = 0;
+    int32_t *fault = nullptr;                 // device: set by a leaf walk that met a NaN / inf / negative category
+    int32_t *fault_host = nullptr;            // pinned mirror for bark_ctx_status
+};
+
+namespace bark {
+
+// ctx valid and made for the current device?  (entry points call this first)
+int check_ctx(const bark_ctx *ctx);
+int ctx_events(bark_ctx *ctx, size_t n);          // at least n events in ctx->events
+int ctx_chain_streams(bark_ctx *ctx, size_t n);   // at least n chain streams + events
+int set_lds_limits();                             // once per device: kernels with > 64 KiB of dynamic LDS (chol.hip)
 
 constexpr int NODE_BYTES = 26;          // forest.py:8-19, packed
 constexpr uint32_t LEAF_FLAG = 0x80000000u;

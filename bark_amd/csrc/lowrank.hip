@@ -19,7 +19,7 @@
 
 namespace bark {
 int walk_one_hot(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d, int words,
-                 uint32_t *out, hipStream_t stream);  // traverse.hip
+                 uint32_t *out, int32_t *fault, hipStream_t stream);  // traverse.hip
 
 namespace {
 
@@ -417,9 +417,12 @@ __global__ __launch_bounds__(LR_THREADS) void small_kernel(const double *__restr
 // M = Y den^-1 (N x r): one thread per entry, den^-1 in LDS.
 __global__ __launch_bounds__(LR_THREADS) void left_factor_kernel(const double *__restrict__ Y,
                                                                  const double *__restrict__ inv, int N, int r,
-                                                                 double *__restrict__ M, Chain ch, ChainInts accept) {
+                                                                 double *__restrict__ M, Chain ch, ChainInts accept,
+                                                                 const int32_t *__restrict__ accept_dev) {
     __shared__ double is[LR_MAX * LR_MAX];
-    if (!accept.v[blockIdx.y]) return;  // chain = blockIdx.y (uniform per workgroup)
+    // chain = blockIdx.y (uniform per workgroup); the decision comes from the host (accept) or, in a device-side
+    // sweep, from decide_kernel's flags (accept_dev, > 0 = accepted)
+    if (accept_dev ? accept_dev[blockIdx.y] <= 0 : !accept.v[blockIdx.y]) return;
     Y += blockIdx.y * ch.ws;
     inv += blockIdx.y * ch.ws;
     M += blockIdx.y * ch.ws;
@@ -437,9 +440,10 @@ __global__ __launch_bounds__(LR_THREADS) void left_factor_kernel(const double *_
 __global__ __launch_bounds__(LR_THREADS) void rank_update_kernel(const double *__restrict__ K,
                                                                  const double *__restrict__ M,
                                                                  const double *__restrict__ R, int N, int r,
-                                                                 double *__restrict__ out, Chain ch, ChainInts accept) {
+                                                                 double *__restrict__ out, Chain ch, ChainInts accept,
+                                                                 const int32_t *__restrict__ accept_dev) {
     extern __shared__ __attribute__((aligned(16))) double strips[];  // Ms[64][r] | Rs[64][r]
-    if (!accept.v[blockIdx.z]) return;  // chain = blockIdx.z (uniform per workgroup)
+    if (accept_dev ? accept_dev[blockIdx.z] <= 0 : !accept.v[blockIdx.z]) return;  // chain = blockIdx.z
     K += blockIdx.z * ch.k;
     out += blockIdx.z * ch.k;
     M += blockIdx.z * ch.ws;
@@ -553,12 +557,37 @@ ChainInts one_int(int v) {
 
 // M = Y den^-1, then out = K - M R'  for the chains whose accept entry is set
 void launch_rewrite(hipStream_t stream, const double *K, int N, int r, const double *Y, const double *inv, double *M,
-                    const double *R, double *out, const ChainInts &accept, int nc = 1, Chain ch = Chain{0, 0}) {
+                    const double *R, double *out, const ChainInts &accept, int nc = 1, Chain ch = Chain{0, 0},
+                    const int32_t *accept_dev = nullptr) {
     hipLaunchKernelGGL(left_factor_kernel, dim3((unsigned)(((size_t)N * r + LR_THREADS - 1) / LR_THREADS), (unsigned)nc),
-                       dim3(LR_THREADS), 0, stream, Y, inv, N, r, M, ch, accept);
+                       dim3(LR_THREADS), 0, stream, Y, inv, N, r, M, ch, accept, accept_dev);
     const unsigned tiles = (unsigned)((N + 63) / 64);
     hipLaunchKernelGGL(rank_update_kernel, dim3(tiles, tiles, (unsigned)nc), dim3(LR_THREADS),
-                       (size_t)2 * 64 * r * sizeof(double), stream, K, M, R, N, r, out, ch, accept);
+                       (size_t)2 * 64 * r * sizeof(double), stream, K, M, R, N, r, out, ch, accept, accept_dev);
+}
+
+// Metropolis decision of one tree proposal per chain on the device (bark_sampler.py:256-264):
+//   log_alpha = log_q_prior + (new_mll - cur_mll),  new_mll - cur_mll = 0.5 (dquad - dlogdet)   (scalars = {dquad, dlogdet})
+//   accept iff log(u) <= min(log_alpha, 0);  on accept the chain's running y'K^-1 y and log|K| move with it.
+// accept_out: 1 / 0, or -1 when the r x r system was singular (the reference raises LinAlgError there).
+__global__ void decide_kernel(const double *__restrict__ scalars, const double *__restrict__ log_q_prior,
+                              const double *__restrict__ log_u, const int *__restrict__ flags, size_t flag_stride_ints,
+                              int nc, double *__restrict__ state, int32_t *__restrict__ accept_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nc) return;
+    const double dquad = scalars[2 * b], dlogdet = scalars[2 * b + 1];
+    int acc;
+    if (flags[(size_t)b * flag_stride_ints] != 0) {
+        acc = -1;
+    } else {
+        const double log_alpha = log_q_prior[b] + 0.5 * (dquad - dlogdet);
+        acc = (log_u[b] <= fmin(log_alpha, 0.0)) ? 1 : 0;  // NaN compares false: reject
+    }
+    accept_out[b] = acc;
+    if (acc > 0) {
+        state[2 * b] = state[2 * b] - dquad;
+        state[2 * b + 1] = state[2 * b + 1] + dlogdet;
+    }
 }
 
 void launch_skinny_t(hipStream_t stream, const double *K, const double *U, int N, int r, double *out) {
@@ -649,6 +678,19 @@ int bark_lowrank_update_hip(const double *K_inv, int64_t N, const double *U, int
     return BARK_OK;
 }
 
+// Reads the `singular` flag the last update / swap evaluation left in `workspace` (synchronises `stream`):
+// *singular_out = 1-based column of the first exactly-zero pivot of (mul I + U' K_inv U), or 0.  The reference's
+// np.linalg.solve / slogdet raise LinAlgError there (quick_inverse.py:19,31); the Python layer does the same.
+int bark_lowrank_status_hip(void *workspace, int64_t N, int64_t r, int32_t *singular_out, void *stream_) {
+    error_buffer()[0] = 0;
+    if (!workspace || !singular_out || N < 1 || r < 1 || r > LR_MAX) return fail(BARK_ERR_ARG, "bark_lowrank_status_hip: bad argument");
+    const LowRankWs w = lowrank_ws(workspace, N, r);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    BARK_HIP_CHECK(hipMemcpyAsync(singular_out, w.flag, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    BARK_HIP_CHECK(hipStreamSynchronize(stream));
+    return BARK_OK;
+}
+
 // ---- fused tree swap (the per-tree step of the sampler, bark_sampler.py:233-257) -----------------
 // The reference evaluates a proposal by  subtract(U_old) -> add(U_new) -> mll  (2 Woodbury + 2 determinant
 // updates + one quadratic form, ~9 passes over the N x N inverse) before it knows whether to accept.
@@ -705,10 +747,14 @@ size_t bark_tree_swap_workspace_bytes(int64_t N, int64_t r) {
     return base + round_up((int64_t)((size_t)N * r * sizeof(double)), 256) + codes;
 }
 
-int bark_tree_swap_eval_hip(const double *K_inv, int64_t N, const void *packed, const bark_pack_info *info,
+int bark_tree_swap_eval_hip(bark_ctx *ctx, const double *K_inv, int64_t N, const void *packed, const bark_pack_info *info,
                             const double *X, int64_t d, int64_t r_old, double s, const double *y, double *scalars_out,
                             void *workspace, size_t workspace_bytes, void *stream_) {
     error_buffer()[0] = 0;
+    {
+        const int crc = check_ctx(ctx);
+        if (crc) return crc;
+    }
     if (!K_inv || !packed || !info || !X || !y || !scalars_out || !workspace || N < 1 || d < 1 || N > (1 << 24))
         return fail(BARK_ERR_ARG, "bark_tree_swap_eval_hip: bad argument");
     if (info->B != 1 || info->m != 2)
@@ -723,7 +769,7 @@ int bark_tree_swap_eval_hip(const double *K_inv, int64_t N, const void *packed, 
     double *U = reinterpret_cast<double *>(ws + base);
     uint32_t *codes = reinterpret_cast<uint32_t *>(ws + base + round_up((int64_t)((size_t)N * r * sizeof(double)), 256));
     const int words = (int)((r + 31) / 32);
-    int rc = walk_one_hot(packed, info, X, N, d, words, codes, stream);
+    int rc = walk_one_hot(packed, info, X, N, d, words, codes, ctx->fault, stream);
     if (rc) return rc;
     ChainDoubles scales = {};
     scales.v[0] = s;
@@ -742,33 +788,6 @@ int bark_tree_swap_eval_hip(const double *K_inv, int64_t N, const void *packed, 
 // bark_tree_swap_chains_workspace_bytes(N, info->max_bits, nc) bytes.  With N even and <= 16 leaves per pair the
 // chain index is a grid dimension of every kernel (one launch sequence for all chains); otherwise one
 // single-chain sequence per chain, each on its own stream.
-namespace {
-struct ChainStreams {
-    std::vector<hipStream_t> streams;
-    std::vector<hipEvent_t> done;
-    hipEvent_t fork = nullptr;
-};
-
-int chain_streams(ChainStreams **out, size_t n) {
-    static thread_local ChainStreams per_device[32];
-    int dev = 0;
-    BARK_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 32) return fail(BARK_ERR_ARG, "device index %d out of range", dev);
-    ChainStreams &c = per_device[dev];
-    if (!c.fork) BARK_HIP_CHECK(hipEventCreateWithFlags(&c.fork, hipEventDisableTiming));
-    while (c.streams.size() < n) {
-        hipStream_t st;
-        hipEvent_t ev;
-        BARK_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        BARK_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        c.streams.push_back(st);
-        c.done.push_back(ev);
-    }
-    *out = &c;
-    return BARK_OK;
-}
-}  // namespace
-
 size_t bark_tree_swap_chains_workspace_bytes(int64_t N, int64_t r, int64_t nc, size_t *chain_stride_bytes) {
     if (N < 1 || r < 1 || r > LR_MAX || nc < 1 || nc > MAX_CHAINS) return 0;
     const size_t stride = (size_t)round_up((int64_t)bark_tree_swap_workspace_bytes(N, r), 256);
@@ -777,24 +796,15 @@ size_t bark_tree_swap_chains_workspace_bytes(int64_t N, int64_t r, int64_t nc, s
     return stride * (size_t)nc + (size_t)nc * (size_t)((r + 31) / 32) * (size_t)bark_leaf_npad(N) * sizeof(uint32_t);
 }
 
-int bark_tree_swap_eval_chains_hip(const double *K_inv, int64_t N, int64_t nc, const void *packed,
-                                   const bark_pack_info *info, const double *X, int64_t d, const int64_t *r_old,
-                                   const double *s, const double *y, double *scalars_out, void *workspace,
-                                   size_t workspace_bytes, void *stream_) {
-    error_buffer()[0] = 0;
-    if (!K_inv || !packed || !info || !X || !r_old || !s || !y || !scalars_out || !workspace || N < 1 || d < 1 || nc < 1 ||
-        nc > MAX_CHAINS || N > (1 << 24))
-        return fail(BARK_ERR_ARG, "bark_tree_swap_eval_chains_hip: bad argument (1 <= chains <= %d)", MAX_CHAINS);
-    if (info->B != nc || info->m != 2) return fail(BARK_ERR_ARG, "pack one [old tree, new tree] pair per chain (B = chains, m = 2)");
+}  // extern "C"
+
+// One proposal per chain: leaf walk of the nc [old, new] pairs, U, Y = K_inv U, the r x r algebra -> scalars_out
+// (nc, 2).  Chain b's workspace block starts `stride` bytes after chain b-1's (>= the block size for this r); the
+// codes of all chains follow at ws + stride * nc.
+static int eval_chains(bark_ctx *ctx, const double *K_inv, int64_t N, int64_t nc, const void *packed, const bark_pack_info *info,
+                       const double *X, int64_t d, const int64_t *r_old, const double *s, const double *y,
+                       double *scalars_out, char *ws, size_t stride, hipStream_t caller) {
     const int64_t r = info->max_bits;
-    if (r < 2 || r > LR_MAX) return fail(BARK_ERR_ARG, "tree swap supports 2..%d leaves in total (got %lld)", LR_MAX, (long long)r);
-    for (int64_t b = 0; b < nc; ++b)
-        if (r_old[b] < 1 || r_old[b] >= r) return fail(BARK_ERR_ARG, "chain %lld: r_old = %lld is not inside (0, %lld)", (long long)b, (long long)r_old[b], (long long)r);
-    size_t stride = 0;
-    if (workspace_bytes < bark_tree_swap_chains_workspace_bytes(N, r, nc, &stride))
-        return fail(BARK_ERR_WORKSPACE, "tree-swap workspace too small for %lld chains", (long long)nc);
-    hipStream_t caller = static_cast<hipStream_t>(stream_);
-    char *ws = static_cast<char *>(workspace);
     if (colsum_usable(N, r)) {
         // one launch sequence for all chains: the chain index is a grid dimension of every kernel
         const Chain ch{(size_t)N * (size_t)N, stride / sizeof(double)};
@@ -803,7 +813,7 @@ int bark_tree_swap_eval_chains_hip(const double *K_inv, int64_t N, int64_t nc, c
         double *U = reinterpret_cast<double *>(ws + base);
         uint32_t *codes = reinterpret_cast<uint32_t *>(ws + stride * (size_t)nc);
         const int words = (int)((r + 31) / 32);
-        int rc = walk_one_hot(packed, info, X, N, d, words, codes, caller);
+        int rc = walk_one_hot(packed, info, X, N, d, words, codes, ctx->fault, caller);
         if (rc) return rc;
         ChainDoubles scales = {};
         ChainInts r_negs = {};
@@ -823,22 +833,105 @@ int bark_tree_swap_eval_chains_hip(const double *K_inv, int64_t N, int64_t nc, c
         return BARK_OK;
     }
     // general shapes (odd N, more than 16 leaves): one single-chain sequence per chain, each on its own stream
-    ChainStreams *cs = nullptr;
-    int rc = chain_streams(&cs, (size_t)nc);
+    int rc = ctx_chain_streams(ctx, (size_t)nc);
     if (rc) return rc;
-    BARK_HIP_CHECK(hipEventRecord(cs->fork, caller));
+    BARK_HIP_CHECK(hipEventRecord(ctx->chain_fork, caller));
     bark_pack_info one = *info;
     one.B = 1;
     for (int64_t b = 0; b < nc; ++b) {
-        hipStream_t st = cs->streams[(size_t)b];
-        BARK_HIP_CHECK(hipStreamWaitEvent(st, cs->fork, 0));
-        rc = bark_tree_swap_eval_hip(K_inv + (size_t)b * N * N, N,
+        hipStream_t st = ctx->chain_streams[(size_t)b];
+        BARK_HIP_CHECK(hipStreamWaitEvent(st, ctx->chain_fork, 0));
+        rc = bark_tree_swap_eval_hip(ctx, K_inv + (size_t)b * N * N, N,
                                      static_cast<const char *>(packed) + (size_t)b * 2 * info->stride * 16, &one, X, d,
                                      r_old[b], s[b], y, scalars_out + 2 * b, ws + (size_t)b * stride, stride, st);
         // the join is recorded even after a failure so that the caller's stream never waits on nothing
-        BARK_HIP_CHECK(hipEventRecord(cs->done[(size_t)b], st));
-        BARK_HIP_CHECK(hipStreamWaitEvent(caller, cs->done[(size_t)b], 0));
+        BARK_HIP_CHECK(hipEventRecord(ctx->chain_done[(size_t)b], st));
+        BARK_HIP_CHECK(hipStreamWaitEvent(caller, ctx->chain_done[(size_t)b], 0));
         if (rc) return rc;
+    }
+    return BARK_OK;
+}
+
+extern "C" {
+
+int bark_tree_swap_eval_chains_hip(bark_ctx *ctx, const double *K_inv, int64_t N, int64_t nc, const void *packed,
+                                   const bark_pack_info *info, const double *X, int64_t d, const int64_t *r_old,
+                                   const double *s, const double *y, double *scalars_out, void *workspace,
+                                   size_t workspace_bytes, void *stream_) {
+    error_buffer()[0] = 0;
+    {
+        const int crc = check_ctx(ctx);
+        if (crc) return crc;
+    }
+    if (!K_inv || !packed || !info || !X || !r_old || !s || !y || !scalars_out || !workspace || N < 1 || d < 1 || nc < 1 ||
+        nc > MAX_CHAINS || N > (1 << 24))
+        return fail(BARK_ERR_ARG, "bark_tree_swap_eval_chains_hip: bad argument (1 <= chains <= %d)", MAX_CHAINS);
+    if (info->B != nc || info->m != 2) return fail(BARK_ERR_ARG, "pack one [old tree, new tree] pair per chain (B = chains, m = 2)");
+    const int64_t r = info->max_bits;
+    if (r < 2 || r > LR_MAX) return fail(BARK_ERR_ARG, "tree swap supports 2..%d leaves in total (got %lld)", LR_MAX, (long long)r);
+    for (int64_t b = 0; b < nc; ++b)
+        if (r_old[b] < 1 || r_old[b] >= r) return fail(BARK_ERR_ARG, "chain %lld: r_old = %lld is not inside (0, %lld)", (long long)b, (long long)r_old[b], (long long)r);
+    size_t stride = 0;
+    if (workspace_bytes < bark_tree_swap_chains_workspace_bytes(N, r, nc, &stride))
+        return fail(BARK_ERR_WORKSPACE, "tree-swap workspace too small for %lld chains", (long long)nc);
+    return eval_chains(ctx, K_inv, N, nc, packed, info, X, d, r_old, s, y, scalars_out, static_cast<char *>(workspace), stride,
+                       static_cast<hipStream_t>(stream_));
+}
+
+// One sweep over the trees of nc chains with the Metropolis decision taken on the device — the per-tree loop of
+// bark_sampler.py:233-264 without a host round trip per tree.  Step t (t < n_steps) swaps one tree per chain:
+//   packed + packed_offsets[t], infos[t]   wire format of the nc pairs [old tree, new tree] of that step (B = nc, m = 2)
+//   r_old[t * nc + b]                      leaves of chain b's old tree (HOST)
+//   log_q_prior, log_u                     (n_steps, nc) DEVICE: proposal ratio and log of the uniform draw
+// For every step: evaluate (as bark_tree_swap_eval_chains_hip), decide (decide_kernel), rewrite K_inv[b] for the
+// accepted chains.  state (nc, 2) DEVICE holds y'K^-1 y and log|K| of every chain on entry and exit;
+// accept_out (n_steps, nc) DEVICE int32: 1 accepted, 0 rejected, -1 singular system.  Nothing synchronises: the host
+// reads accept_out and state once per sweep.  workspace: bark_tree_swap_chains_workspace_bytes(N, r_max, nc) bytes with
+// r_max = max_t infos[t].max_bits, plus 16 * nc bytes for the step's scalars.
+int bark_tree_sweep_chains_hip(bark_ctx *ctx, double *K_inv, int64_t N, int64_t nc, int64_t n_steps, const void *packed,
+                               const int64_t *packed_offsets, const bark_pack_info *infos, const double *X, int64_t d,
+                               const int64_t *r_old, const double *s, const double *y, const double *log_q_prior,
+                               const double *log_u, double *state, int32_t *accept_out, void *workspace,
+                               size_t workspace_bytes, void *stream_) {
+    error_buffer()[0] = 0;
+    {
+        const int crc = check_ctx(ctx);
+        if (crc) return crc;
+    }
+    if (!K_inv || !packed || !packed_offsets || !infos || !X || !r_old || !s || !y || !log_q_prior || !log_u || !state ||
+        !accept_out || !workspace || N < 1 || d < 1 || nc < 1 || nc > MAX_CHAINS || n_steps < 1 || N > (1 << 24))
+        return fail(BARK_ERR_ARG, "bark_tree_sweep_chains_hip: bad argument (1 <= chains <= %d)", MAX_CHAINS);
+    int64_t r_max = 0;
+    for (int64_t t = 0; t < n_steps; ++t) {
+        const bark_pack_info &in = infos[t];
+        if (in.B != nc || in.m != 2) return fail(BARK_ERR_ARG, "step %lld: pack one [old, new] pair per chain (B = chains, m = 2)", (long long)t);
+        if (in.max_bits < 2 || in.max_bits > LR_MAX)
+            return fail(BARK_ERR_ARG, "step %lld: tree swap supports 2..%d leaves in total (got %lld)", (long long)t, LR_MAX, (long long)in.max_bits);
+        for (int64_t b = 0; b < nc; ++b)
+            if (r_old[t * nc + b] < 1 || r_old[t * nc + b] >= in.max_bits)
+                return fail(BARK_ERR_ARG, "step %lld chain %lld: r_old out of range", (long long)t, (long long)b);
+        if (in.max_bits > r_max) r_max = in.max_bits;
+    }
+    size_t stride = 0;
+    const size_t need = bark_tree_swap_chains_workspace_bytes(N, r_max, nc, &stride);
+    if (workspace_bytes < need + 16 * (size_t)nc) return fail(BARK_ERR_WORKSPACE, "tree-sweep workspace too small");
+    hipStream_t caller = static_cast<hipStream_t>(stream_);
+    char *ws = static_cast<char *>(workspace);
+    double *scalars = reinterpret_cast<double *>(ws + need);
+    const Chain ch{(size_t)N * (size_t)N, stride / sizeof(double)};
+    for (int64_t t = 0; t < n_steps; ++t) {
+        const bark_pack_info &in = infos[t];
+        const int64_t r = in.max_bits;
+        int rc = eval_chains(ctx, K_inv, N, nc, static_cast<const char *>(packed) + packed_offsets[t], &in, X, d, r_old + t * nc, s,
+                             y, scalars, ws, stride, caller);
+        if (rc) return rc;
+        const LowRankWs w = lowrank_ws(ws, N, r);
+        int32_t *acc = accept_out + t * nc;
+        hipLaunchKernelGGL(decide_kernel, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, caller, scalars, log_q_prior + t * nc,
+                           log_u + t * nc, w.flag, stride / sizeof(int), (int)nc, state, acc);
+        BARK_LAUNCH_CHECK();
+        launch_rewrite(caller, K_inv, (int)N, (int)r, w.Y, w.inv, w.M, w.Y, K_inv, ChainInts{}, (int)nc, ch, acc);
+        BARK_LAUNCH_CHECK();
     }
     return BARK_OK;
 }

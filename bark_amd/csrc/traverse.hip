@@ -20,14 +20,17 @@ namespace {
 constexpr int WALK_THREADS = 256;
 
 template <bool X_IN_LDS>
-__device__ __forceinline__ uint4 walk_tree(const uint4 *__restrict__ tree, int max_depth, const double *xrow) {
+__device__ __forceinline__ uint4 walk_tree(const uint4 *__restrict__ tree, int max_depth, const double *xrow,
+                                           int32_t *__restrict__ fault) {
     uint4 n = tree[0];
     for (int step = 0; step < max_depth && !(n.x & LEAF_FLAG); ++step) {
         const uint32_t f = n.x & FEAT_MASK;
         const double xv = xrow[f];
         bool left;
         if (n.x & CAT_FLAG) {
-            const double xt = trunc(xv);  // int(): toward zero; NaN/negative never match (host rejects them)
+            const double xt = trunc(xv);  // int(): toward zero
+            // `1 << int(x)` raises in the reference for NaN / inf / x <= -1 (forest.py:38): flag it, the host raises
+            if (!(xt >= 0.0 && xt < INFINITY)) *fault = 1;
             left = (xt >= 0.0 && xt < 32.0) ? ((n.y >> (uint32_t)xt) & 1u) : false;
         } else {
             left = xv <= (double)__uint_as_float(n.y);
@@ -46,7 +49,8 @@ template <int MODE, bool X_IN_LDS>
 __global__ __launch_bounds__(WALK_THREADS) void leaf_walk_kernel(const uint4 *__restrict__ nodes, int stride, int m,
                                                                  int max_depth, const double *__restrict__ X, int N,
                                                                  int d, int npad, int words,
-                                                                 uint32_t *__restrict__ out) {
+                                                                 uint32_t *__restrict__ out,
+                                                                 int32_t *__restrict__ fault) {
     extern __shared__ __attribute__((aligned(16))) double xs[];
     const int tid = threadIdx.x;
     const int i = blockIdx.x * WALK_THREADS + tid;
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(WALK_THREADS) void leaf_walk_kernel(const uint4 *__
     if (MODE == 0) {
         if (!live) return;
         uint32_t *o = out + ((size_t)b * N + i) * m;
-        for (int t = 0; t < m; ++t) o[t] = walk_tree<X_IN_LDS>(forest + (size_t)t * stride, max_depth, xrow).y;
+        for (int t = 0; t < m; ++t) o[t] = walk_tree<X_IN_LDS>(forest + (size_t)t * stride, max_depth, xrow, fault).y;
     } else if (MODE == 2) {
         if (i >= npad) return;
         uint32_t *o = out + (size_t)b * words * npad + i;
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(WALK_THREADS) void leaf_walk_kernel(const uint4 *__
         uint32_t accw = 0;
         if (live) {
             for (int t = 0; t < m; ++t) {
-                const uint32_t bit = walk_tree<X_IN_LDS>(forest + (size_t)t * stride, max_depth, xrow).z;
+                const uint32_t bit = walk_tree<X_IN_LDS>(forest + (size_t)t * stride, max_depth, xrow, fault).z;
                 const int w = (int)(bit >> 5);
                 while (cur < w && cur < words) {  // monotone: earlier words are complete
                     o[(size_t)cur * npad] = accw;
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(WALK_THREADS) void leaf_walk_kernel(const uint4 *__
                 for (int q = 0; q < 4; ++q) {
                     const int t = w * 4 + q;
                     if (t < m) {
-                        const uint4 leaf = walk_tree<X_IN_LDS>(forest + (size_t)t * stride, max_depth, xrow);
+                        const uint4 leaf = walk_tree<X_IN_LDS>(forest + (size_t)t * stride, max_depth, xrow, fault);
                         word |= (leaf.x & 0xFFu) << (8 * q);
                     }
                 }
@@ -116,8 +120,8 @@ __global__ __launch_bounds__(WALK_THREADS) void leaf_walk_kernel(const uint4 *__
 
 template <int MODE>
 int launch_walk(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d, uint32_t *out,
-                void *stream, int force_words = 0) {
-    if (!packed || !info || !X || !out) return fail(BARK_ERR_ARG, "leaf walk: null argument");
+                int32_t *fault, void *stream, int force_words = 0) {
+    if (!packed || !info || !X || !out || !fault) return fail(BARK_ERR_ARG, "leaf walk: null argument");
     if (N < 1 || d < 1 || N > (1 << 30)) return fail(BARK_ERR_ARG, "leaf walk: bad N=%lld d=%lld", (long long)N, (long long)d);
     if (info->B > 65535) return fail(BARK_ERR_ARG, "leaf walk: at most 65535 forests per call (got %lld)", (long long)info->B);
     const int64_t npad = bark_leaf_npad(N);
@@ -132,10 +136,10 @@ int launch_walk(const void *packed, const bark_pack_info *info, const double *X,
     const uint4 *nodes = static_cast<const uint4 *>(packed);
     if (lds <= 64 * 1024) {
         hipLaunchKernelGGL((leaf_walk_kernel<MODE, true>), grid, dim3(WALK_THREADS), lds, s, nodes, (int)info->stride,
-                           (int)info->m, (int)info->max_depth, X, (int)N, (int)d, (int)npad, words, out);
+                           (int)info->m, (int)info->max_depth, X, (int)N, (int)d, (int)npad, words, out, fault);
     } else {
         hipLaunchKernelGGL((leaf_walk_kernel<MODE, false>), grid, dim3(WALK_THREADS), 0, s, nodes, (int)info->stride,
-                           (int)info->m, (int)info->max_depth, X, (int)N, (int)d, (int)npad, words, out);
+                           (int)info->m, (int)info->max_depth, X, (int)N, (int)d, (int)npad, words, out, fault);
     }
     BARK_LAUNCH_CHECK();
     return BARK_OK;
@@ -145,8 +149,16 @@ int launch_walk(const void *packed, const bark_pack_info *info, const double *X,
 
 // one-hot leaf code with `words` = ceil(max_bits / 32) planes, whatever encoding the Gram kernels would pick
 int walk_one_hot(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d, int words,
-                 uint32_t *out, hipStream_t stream) {
-    return launch_walk<2>(packed, info, X, N, d, out, stream, words);
+                 uint32_t *out, int32_t *fault, hipStream_t stream) {
+    return launch_walk<2>(packed, info, X, N, d, out, fault, stream, words);
+}
+
+// Gram-kernel leaf codes (encoding chosen from `info`), for the sweep entry points that already hold a context
+int walk_codes(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d, uint32_t *out,
+               int32_t *fault, hipStream_t stream) {
+    if (!info) return fail(BARK_ERR_ARG, "leaf codes: null info");
+    return bark_leaf_encoding(info) == BARK_LEAF_BITS ? launch_walk<2>(packed, info, X, N, d, out, fault, stream)
+                                                      : launch_walk<1>(packed, info, X, N, d, out, fault, stream);
 }
 
 }  // namespace bark
@@ -157,10 +169,12 @@ extern "C" {
 
 int64_t bark_leaf_npad(int64_t N) { return round_up(N, TILE); }
 
-int bark_leaf_indices_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
-                          uint32_t *out, void *stream) {
+int bark_leaf_indices_hip(bark_ctx *ctx, const void *packed, const bark_pack_info *info, const double *X, int64_t N,
+                          int64_t d, uint32_t *out, void *stream) {
     error_buffer()[0] = 0;
-    return launch_walk<0>(packed, info, X, N, d, out, stream);
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    return launch_walk<0>(packed, info, X, N, d, out, ctx->fault, stream);
 }
 
 // One-hot bits cost 2 VALU per 32 bits in the Gram kernels, packed bytes 4 (6 with ids >= 128) per 4 trees:
@@ -176,12 +190,35 @@ int64_t bark_leaf_words(const bark_pack_info *info) {
     return bark_leaf_encoding(info) == BARK_LEAF_BITS ? (info->max_bits + 31) / 32 : (info->m + 3) / 4;
 }
 
-int bark_leaf_codes_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
-                        uint32_t *out, void *stream) {
+int bark_leaf_codes_hip(bark_ctx *ctx, const void *packed, const bark_pack_info *info, const double *X, int64_t N,
+                        int64_t d, uint32_t *out, void *stream) {
     error_buffer()[0] = 0;
-    if (!info) return fail(BARK_ERR_ARG, "leaf codes: null info");
-    return bark_leaf_encoding(info) == BARK_LEAF_BITS ? launch_walk<2>(packed, info, X, N, d, out, stream)
-                                                      : launch_walk<1>(packed, info, X, N, d, out, stream);
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    return walk_codes(packed, info, X, N, d, out, ctx->fault, static_cast<hipStream_t>(stream));
+}
+
+// out[i * ldo + c] = value if leaves[i * ldl] == ids[c] else 0 — the one-hot leaf vectors of forest.py:70-75
+// (`np.equal(leaves[:, None], all_leaves[None, :])`), optionally scaled (bark_sampler.py:233-236 `* s_sqrtm`).
+__global__ void onehot_match_kernel(const uint32_t *__restrict__ leaves, int64_t N, int64_t ldl,
+                                    const uint32_t *__restrict__ ids, int r, double value, double *__restrict__ out,
+                                    int64_t ldo) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N * r) return;
+    const int64_t i = e / r;
+    const int c = (int)(e - i * r);
+    out[i * ldo + c] = leaves[i * ldl] == ids[c] ? value : 0.0;
+}
+
+int bark_onehot_match_hip(const uint32_t *leaves, int64_t N, int64_t ldl, const uint32_t *ids, int64_t r, double value,
+                          double *out, int64_t ldo, void *stream) {
+    error_buffer()[0] = 0;
+    if (!leaves || !ids || !out || N < 1 || r < 1 || ldl < 1 || ldo < r || N * r > ((int64_t)1 << 40))
+        return fail(BARK_ERR_ARG, "bark_onehot_match_hip: bad argument");
+    hipLaunchKernelGGL(onehot_match_kernel, dim3((unsigned)((N * r + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), leaves, N, ldl, ids, (int)r, value, out, ldo);
+    BARK_LAUNCH_CHECK();
+    return BARK_OK;
 }
 
 }  // extern "C"

@@ -52,12 +52,30 @@ def reduce_mixture(mu_local, var_local, total: int, group=None):
         E[Y] = (1/total) sum_b mu_b ;   Var[Y] = (1/total) sum_b (var_b + mu_b^2) - E[Y]^2
 
     One all-reduce(sum) of 2*C float64 partial sums (160 KB at C = 10^4) instead of gathering (B, C) arrays.
-    `mu_local`, `var_local`: (B_local, C) torch tensors on the backend's device."""
+    `mu_local`, `var_local`: (B_local, C) torch tensors on the backend's device.  On the GPU the partial sums and the
+    final moments come from bark_mixture_partial_hip / bark_mixture_finish_hip; CPU tensors (gloo tests) take the
+    same two steps in torch.  `group=False`: no collective (single process)."""
     import torch
     import torch.distributed as dist
 
-    partial = torch.stack([mu_local.sum(dim=0), (var_local + mu_local**2).sum(dim=0)])
-    if dist.is_available() and dist.is_initialized():
+    B, C = int(mu_local.shape[0]), int(mu_local.shape[1])
+    on_gpu = mu_local.is_cuda
+    if on_gpu:
+        from . import _lib
+
+        mu_c, var_c = mu_local.contiguous(), var_local.contiguous()
+        partial = torch.empty((2, C), dtype=torch.float64, device=mu_local.device)
+        _lib.check(_lib.lib().bark_mixture_partial_hip(_lib.ptr(mu_c), _lib.ptr(var_c), B, C, _lib.ptr(partial),
+                                                       _lib.stream_ptr()))
+    else:
+        partial = torch.stack([mu_local.sum(dim=0), (var_local + mu_local**2).sum(dim=0)])
+    if group is not False and dist.is_available() and dist.is_initialized():
         dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=group)
+    if on_gpu:
+        mean = torch.empty(C, dtype=torch.float64, device=mu_local.device)
+        var = torch.empty(C, dtype=torch.float64, device=mu_local.device)
+        _lib.check(_lib.lib().bark_mixture_finish_hip(_lib.ptr(partial), float(total), C, _lib.ptr(mean), _lib.ptr(var),
+                                                      _lib.stream_ptr()))
+        return mean, var
     mean = partial[0] / total
     return mean, partial[1] / total - mean**2

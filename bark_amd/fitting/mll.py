@@ -17,7 +17,7 @@ import os
 import numpy as np
 
 from .. import _lib
-from ..forest import PackedForest, _as_nodes, _check_categorical, _feat_types, _is_torch, _points
+from ..forest import _as_nodes, _feat_types, _is_torch, _points, packed_forest
 
 
 def _feat_types_of(domain_or_feat_types):
@@ -50,8 +50,7 @@ def _fit_chunk(B: int, need, budget_bytes: int | None = None) -> int:
             budget_bytes = int(float(env) * (1 << 30))
         else:
             free, _total = torch.cuda.mem_get_info()
-            cached = _lib._workspace.numel() if _lib._workspace is not None else 0
-            budget_bytes = int(0.7 * (free + cached))
+            budget_bytes = int(0.7 * (free + _lib.workspace_bytes()))  # this thread's scratch counts as free
     if need(B) <= budget_bytes:
         return int(B)
     lo, hi = 1, int(B)
@@ -80,7 +79,6 @@ def _run(forest, noise, scale, X, y, feat_types, flags, cand=None, timing=None, 
     nodes3 = nodes.reshape(-1, *nodes.shape[-2:])
     B = nodes3.shape[0]
     Xd, _ = _points(X, ft.shape[0])
-    _check_categorical(Xd, ft)
     N, d = Xd.shape
     yd = _lib.to_device(y.detach() if _is_torch(y) else np.asarray(y, dtype=np.float64))
     yd = yd.to(torch.float64).reshape(-1).contiguous()
@@ -105,14 +103,13 @@ def _run(forest, noise, scale, X, y, feat_types, flags, cand=None, timing=None, 
         C = N
     elif cand is not None:
         cand_d, _ = _points(cand, ft.shape[0])
-        _check_categorical(cand_d, ft)
         C = cand_d.shape[0]
     if C:
         mu = torch.empty((B, C), dtype=torch.float64, device=Xd.device)
         var = torch.empty((B, C), dtype=torch.float64, device=Xd.device)
         if want_cov:
             cov = torch.empty((B, C, C), dtype=torch.float64, device=Xd.device)
-    pf = PackedForest(nodes3, ft)
+    pf = packed_forest(nodes3, ft)
     Bc = chunk or choose_chunk(B, N, C, pf.m)
     nbytes = int(lib.bark_mll_workspace_bytes(N, C, pf.m, Bc))
     ws = _lib.workspace(nbytes)
@@ -120,16 +117,32 @@ def _run(forest, noise, scale, X, y, feat_types, flags, cand=None, timing=None, 
     info = torch.empty(B, dtype=torch.int32, device=Xd.device)
     tref = ctypes.byref(timing) if timing is not None else None
     _lib.check(lib.bark_mll_batched_hip(
-        _lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(yd), _lib.ptr(noise_d), _lib.ptr(scale_d),
+        _lib.ctx(), _lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(yd), _lib.ptr(noise_d), _lib.ptr(scale_d),
         _lib.ptr(shift_d), flags, _lib.ptr(cand_d), C, _lib.ptr(out), _lib.ptr(mu), _lib.ptr(var), _lib.ptr(cov),
         _lib.ptr(info),
         _lib.ptr(ws), ws.numel(), Bc, tref, _lib.stream_ptr()))
-    bad = info.cpu().numpy()
-    if bad.any():
-        b = int(np.flatnonzero(bad)[0])
-        raise np.linalg.LinAlgError(
-            f"kernel matrix of forest sample {b} is not positive definite (pivot {int(bad[b])} <= 0)")
+    _raise_on_info(info, "kernel matrix")
     return (out, mu, var, cov) if want_cov else (out, mu, var)
+
+
+def _raise_on_info(info, what: str):
+    """info_out of the sweep entry points: -1 = invalid categorical value met by a leaf walk (ValueError, as the
+    reference's `1 << int(x)`), k > 0 = first non-positive pivot (LinAlgError, as np.linalg.inv on a singular matrix)."""
+    bad = info.cpu().numpy()
+    if not bad.any():
+        return
+    if (bad < 0).any():
+        _clear_fault()  # read-and-reset, so the next call starts clean
+        raise ValueError("categorical feature value is negative, NaN or inf")
+    b = int(np.flatnonzero(bad)[0])
+    raise np.linalg.LinAlgError(f"{what} of forest sample {b} is not positive definite (pivot {int(bad[b])} <= 0)")
+
+
+def _clear_fault():
+    try:
+        _lib.check_categorical_fault()
+    except ValueError:
+        pass
 
 
 def batched_kernel_inverse(forest, noise, scale, X, y, feat_types, *, no_null: bool = True, return_device=False,
@@ -176,7 +189,11 @@ def _inverse_results(mll_noconst, K_inv_y, K_inv, X, y, return_device):
     import torch
 
     yd = _lib.to_device(y.detach() if _is_torch(y) else np.asarray(y, dtype=np.float64)).to(torch.float64).reshape(-1)
-    logdet = -2.0 * mll_noconst - K_inv_y @ yd
+    yd = yd.contiguous()
+    B, N = K_inv_y.shape
+    logdet = torch.empty(B, dtype=torch.float64, device=K_inv_y.device)  # -(y' K^-1 y) - 2 mll per forest sample
+    _lib.check(_lib.lib().bark_rowdot_hip(_lib.ptr(K_inv_y), B, N, N, _lib.ptr(yd), -1.0, _lib.ptr(mll_noconst.contiguous()),
+                                          -2.0, _lib.ptr(logdet), _lib.stream_ptr()))
     if return_device or _is_torch(X):
         return K_inv, K_inv_y, logdet
     return K_inv.cpu().numpy(), K_inv_y.cpu().numpy(), logdet.cpu().numpy()
@@ -194,7 +211,6 @@ def _run_leafspace(forest, noise, scale, X, y, feat_types, flags, chunk=None, ca
     nodes3 = nodes.reshape(-1, *nodes.shape[-2:])
     B = nodes3.shape[0]
     Xd, _ = _points(X, ft.shape[0])
-    _check_categorical(Xd, ft)
     N, d = Xd.shape
     yd = _lib.to_device(y.detach() if _is_torch(y) else np.asarray(y, dtype=np.float64))
     yd = yd.to(torch.float64).reshape(-1).contiguous()
@@ -208,11 +224,10 @@ def _run_leafspace(forest, noise, scale, X, y, feat_types, flags, chunk=None, ca
     cand_d = mu = var = None
     if cand is not None:
         cand_d, _ = _points(cand, ft.shape[0])
-        _check_categorical(cand_d, ft)
         C = cand_d.shape[0]
         mu = torch.empty((B, C), dtype=torch.float64, device=Xd.device)
         var = torch.empty((B, C), dtype=torch.float64, device=Xd.device)
-    pf = PackedForest(nodes3, ft)
+    pf = packed_forest(nodes3, ft)
     R = int(pf.info.max_bits)
     out = torch.empty(B, dtype=torch.float64, device=Xd.device)
     info = torch.empty(B, dtype=torch.int32, device=Xd.device)
@@ -226,21 +241,18 @@ def _run_leafspace(forest, noise, scale, X, y, feat_types, flags, chunk=None, ca
             min(B, max(1, (1 << 30) // max(1, 8 * N * R))),  # keep the (Bc, N, R) row-sum scratch modest
             lambda k: int(lib.bark_kernel_inverse_leafspace_workspace_bytes(N, R, pf.m, k)))
         ws = _lib.workspace(int(lib.bark_kernel_inverse_leafspace_workspace_bytes(N, R, pf.m, Bc)))
-        _lib.check(lib.bark_kernel_inverse_leafspace_hip(_lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(yd),
+        _lib.check(lib.bark_kernel_inverse_leafspace_hip(_lib.ctx(), _lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(yd),
                                                          _lib.ptr(noise_d), _lib.ptr(scale_d), flags, _lib.ptr(out),
                                                          _lib.ptr(K_inv), _lib.ptr(K_inv_y), _lib.ptr(info), _lib.ptr(ws),
                                                          ws.numel(), Bc, _lib.stream_ptr()))
     else:
         Bc = int(chunk) if chunk else _fit_chunk(B, lambda k: int(lib.bark_mll_leafspace_workspace_bytes(N, R, pf.m, k, C)))
         ws = _lib.workspace(int(lib.bark_mll_leafspace_workspace_bytes(N, R, pf.m, Bc, C)))
-        _lib.check(lib.bark_mll_leafspace_hip(_lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(yd),
+        _lib.check(lib.bark_mll_leafspace_hip(_lib.ctx(), _lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(yd),
                                               _lib.ptr(noise_d), _lib.ptr(scale_d), flags, _lib.ptr(cand_d), C,
                                               _lib.ptr(out), _lib.ptr(mu), _lib.ptr(var), _lib.ptr(info),
                                               _lib.ptr(ws), ws.numel(), Bc, _lib.stream_ptr()))
-    bad = info.cpu().numpy()
-    if bad.any():
-        b = int(np.flatnonzero(bad)[0])
-        raise np.linalg.LinAlgError(f"leaf-space system of forest sample {b} is not positive definite")
+    _raise_on_info(info, "leaf-space system")
     if want_inverse:
         return out, K_inv_y, K_inv
     return out if cand is None else (out, mu, var)

@@ -13,6 +13,8 @@ The kernels (csrc/lowrank.hip) are two streaming passes over K_inv around r x r 
 
 from __future__ import annotations
 
+import ctypes
+
 import numpy as np
 
 from .. import _lib
@@ -42,6 +44,10 @@ def _update(K_inv, U, subtract, want_inv, want_det, symmetric=False):
     _lib.check(lib.bark_lowrank_update_hip(_lib.ptr(Kd), N, _lib.ptr(Ud), r, 1 if subtract else 0, 1 if symmetric else 0,
                                            _lib.ptr(out), _lib.ptr(det), _lib.ptr(ws), ws.numel(),
                                            _lib.stream_ptr()))
+    flag = ctypes.c_int32(0)  # np.linalg.solve / slogdet raise on a singular r x r system (quick_inverse.py:19,31)
+    _lib.check(lib.bark_lowrank_status_hip(_lib.ptr(ws), N, r, ctypes.byref(flag), _lib.stream_ptr()))
+    if flag.value:
+        raise np.linalg.LinAlgError("Singular matrix")
     return out, det
 
 

@@ -101,16 +101,15 @@ def _points(X, d_expected=None):
     return t, was_torch
 
 
-def _check_categorical(Xd, ft: np.ndarray):
-    """The reference raises inside `1 << int(x)` for NaN/inf/negative categories (forest.py:38)."""
-    import torch
+def _has_categorical(ft: np.ndarray) -> bool:
+    return bool((ft == FeatureTypeEnum.Cat.value).any())
 
-    cat = np.flatnonzero(ft == FeatureTypeEnum.Cat.value)
-    if cat.size == 0:
-        return
-    v = Xd[:, torch.as_tensor(cat, device=Xd.device)]
-    if bool((~torch.isfinite(v) | (v <= -1.0)).any().item()):
-        raise ValueError("categorical feature value is negative, NaN or inf")
+
+def _raise_on_categorical_fault(ft: np.ndarray):
+    """The reference raises inside `1 << int(x)` for NaN / inf / negative categories (forest.py:38).  The leaf walk
+    flags exactly those evaluations on the device; read the flag back (4 bytes) once the walk is enqueued."""
+    if _has_categorical(ft):
+        _lib.check_categorical_fault()
 
 
 class PackedForest:
@@ -138,12 +137,37 @@ class PackedForest:
         return ctypes.byref(self.info)
 
 
+_PACK_CACHE_MAX_BYTES = 1 << 18  # only small inputs (a tree pair, one forest): hashing 33 MB costs more than packing it
+_PACK_CACHE_ENTRIES = 64
+
+
+def packed_forest(nodes3: np.ndarray, ft: np.ndarray) -> PackedForest:
+    """PackedForest of `nodes3`, reusing the validated + uploaded copy when this thread packed the same bytes before
+    (the sampler evaluates one forest several times: proposal, rebuild on accept, posterior)."""
+    if nodes3.nbytes > _PACK_CACHE_MAX_BYTES:
+        return PackedForest(nodes3, ft)
+    cache = getattr(_lib._tls, "packed", None)
+    if cache is None:
+        from collections import OrderedDict
+
+        cache = _lib._tls.packed = OrderedDict()
+    key = (nodes3.shape, nodes3.tobytes(), ft.tobytes(), _lib.torch_device().index)
+    pf = cache.get(key)
+    if pf is None:
+        pf = cache[key] = PackedForest(nodes3, ft)
+        if len(cache) > _PACK_CACHE_ENTRIES:
+            cache.popitem(last=False)
+    else:
+        cache.move_to_end(key)
+    return pf
+
+
 def pack_forest(nodes, feat_types) -> PackedForest:
     """Validate + repack `(…, m, L)` node records (leading dims flattened to B)."""
     nodes = _as_nodes(nodes, 2)
     ft = _feat_types(feat_types)
     nodes3 = nodes.reshape(-1, *nodes.shape[-2:])
-    return PackedForest(nodes3, ft)
+    return packed_forest(nodes3, ft)
 
 
 def _leaf_codes(pf: PackedForest, Xd):
@@ -155,7 +179,7 @@ def _leaf_codes(pf: PackedForest, Xd):
     npad = int(lib.bark_leaf_npad(N))
     W = int(lib.bark_leaf_words(pf.info_ref))
     out = torch.empty((pf.B, W, npad), dtype=torch.int32, device=Xd.device)
-    _lib.check(lib.bark_leaf_codes_hip(_lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(out),
+    _lib.check(lib.bark_leaf_codes_hip(_lib.ctx(), _lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(out),
                                        _lib.stream_ptr()))
     return out
 
@@ -165,8 +189,8 @@ def _leaf_indices(pf: PackedForest, Xd):
 
     N, d = Xd.shape
     out = torch.empty((pf.B, N, pf.m), dtype=torch.int32, device=Xd.device)
-    _lib.check(_lib.lib().bark_leaf_indices_hip(_lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(out),
-                                                _lib.stream_ptr()))
+    _lib.check(_lib.lib().bark_leaf_indices_hip(_lib.ctx(), _lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d,
+                                                _lib.ptr(out), _lib.stream_ptr()))
     return out
 
 
@@ -184,15 +208,11 @@ def _gram(nodes3, x1, x2, feat_types, *, shift=None, scale=None, noise=None):
     ft = _feat_types(feat_types)
     same = x2 is x1
     X1, t1 = _points(x1, ft.shape[0])
-    _check_categorical(X1, ft)
-    if same:
-        X2 = X1
-    else:
-        X2, _ = _points(x2, ft.shape[0])
-        _check_categorical(X2, ft)
-    pf = PackedForest(nodes3, ft)
+    X2 = X1 if same else _points(x2, ft.shape[0])[0]
+    pf = packed_forest(nodes3, ft)
     l1 = _leaf_codes(pf, X1)
     l2 = l1 if same else _leaf_codes(pf, X2)
+    _raise_on_categorical_fault(ft)
     N, M = X1.shape[0], X2.shape[0]
     out = torch.empty((pf.B, N, M), dtype=torch.float64, device=X1.device)
     dev = lambda v: None if v is None else _lib.to_device(np.ascontiguousarray(v, dtype=np.float64))  # noqa: E731
@@ -213,9 +233,9 @@ def pass_through_forest(nodes, X, feat_types):
         raise ValueError(f"nodes must be (m, node_limit), got {nodes.shape}")
     ft = _feat_types(feat_types)
     Xd, was_torch = _points(X, ft.shape[0])
-    _check_categorical(Xd, ft)
-    pf = PackedForest(nodes[None], ft)
+    pf = packed_forest(nodes[None], ft)
     out = _leaf_indices(pf, Xd)[0]
+    _raise_on_categorical_fault(ft)
     return _out(out, was_torch, np.uint32)
 
 
@@ -241,10 +261,27 @@ def get_leaf_vectors(nodes, X, feat_types):
     if isinstance(leaves, np.ndarray):
         all_leaves = np.unique(leaves)
         return np.equal(leaves[:, None], all_leaves[None, :]).astype(np.float64)
+    return leaf_vectors_device(leaves)
+
+
+def leaf_vectors_device(leaves, value: float = 1.0, out=None, col0: int = 0):
+    """Device form of forest.py:72-75 for a (N,) leaf-index tensor: the distinct leaves are found on the host
+    (np.unique of N * 4 bytes), the (N, r) one-hot matrix — times `value` — is written by bark_onehot_match_hip,
+    optionally into columns col0 .. col0 + r of an existing (N, >= col0 + r) float64 tensor `out`."""
     import torch
 
-    all_leaves = torch.unique(leaves)
-    return (leaves[:, None] == all_leaves[None, :]).to(torch.float64)
+    ids = np.unique(leaves.cpu().numpy().view(np.uint32))
+    r, N = int(ids.shape[0]), int(leaves.shape[0])
+    ids_d = _lib.to_device(ids.view(np.int32))
+    if out is None:
+        out = torch.empty((N, r), dtype=torch.float64, device=leaves.device)
+        col0 = 0
+    if out.shape[0] != N or out.shape[1] < col0 + r or not out.is_contiguous():
+        raise ValueError("leaf_vectors_device: bad output buffer")
+    _lib.check(_lib.lib().bark_onehot_match_hip(_lib.ptr(leaves), N, int(leaves.stride(0)), _lib.ptr(ids_d), r, float(value),
+                                                ctypes.c_void_p(out.data_ptr() + 8 * col0), int(out.shape[1]),
+                                                _lib.stream_ptr()))
+    return out if col0 == 0 and out.shape[1] == r else out[:, col0:col0 + r]
 
 
 def forest_gram_matrix(nodes, x1, x2, feat_types):

@@ -59,6 +59,10 @@ def forest_predict(model, data, candidates, domain, diag: bool = True, method: s
 def mixture_of_gaussians_as_normal(mu, var):
     """tree_gps.py:116-131: moments of the equal-weight mixture over forest samples.
     (B x C elementwise host arithmetic, as in the reference; works on numpy or torch.)"""
+    if _is_torch(mu) and mu.is_cuda:
+        from ..distributed import reduce_mixture
+
+        return reduce_mixture(mu, var, int(mu.shape[0]), group=False)
     if _is_torch(mu):
         mu_y = mu.mean(dim=0)
         var_y = (var + mu**2).mean(dim=0) - mu_y**2

@@ -195,7 +195,7 @@ class Workload:
     def run(self, timing=None):
         L = self._lib
         L.check(self.lib.bark_mll_batched_hip(
-            L.ptr(self.pf.packed), self.pf.info_ref, L.ptr(self.Xd), self.N, self.d, L.ptr(self.yd), L.ptr(self.noise_d),
+            L.ctx(), L.ptr(self.pf.packed), self.pf.info_ref, L.ptr(self.Xd), self.N, self.d, L.ptr(self.yd), L.ptr(self.noise_d),
             L.ptr(self.scale_d), None, self.flags, L.ptr(self.cand_d), self.C, L.ptr(self.mll_d), L.ptr(self.mu_d),
             L.ptr(self.var_d), None, L.ptr(self.info_d), L.ptr(self.ws), self.ws.numel(), self.Bc,
             ctypes.byref(timing) if timing is not None else None, self.stream))
@@ -456,7 +456,7 @@ def extras(args, wl, result, mll_host):
     for it in range(reps + 1):
         if it == 1:
             e0.record()
-        _lib.check(lib.bark_leaf_codes_hip(_lib.ptr(wl.pf.packed), ctypes.byref(sub), _lib.ptr(wl.Xd), N, d,
+        _lib.check(lib.bark_leaf_codes_hip(_lib.ctx(), _lib.ptr(wl.pf.packed), ctypes.byref(sub), _lib.ptr(wl.Xd), N, d,
                                            _lib.ptr(leaves), stream))
         _lib.check(lib.bark_gram_from_leaves_hip(_lib.ptr(leaves), N, _lib.ptr(leaves), N, ctypes.byref(sub), None,
                                                  None, None, _lib.ptr(Kg), N, N * N, stream))
@@ -528,7 +528,7 @@ def extras(args, wl, result, mll_host):
     for it in range(lreps + 1):
         if it == 1:
             l0.record()
-        _lib.check(lib.bark_mll_leafspace_hip(_lib.ptr(pf.packed), pf.info_ref, _lib.ptr(wl.Xd), N, d, _lib.ptr(wl.yd),
+        _lib.check(lib.bark_mll_leafspace_hip(_lib.ctx(), _lib.ptr(pf.packed), pf.info_ref, _lib.ptr(wl.Xd), N, d, _lib.ptr(wl.yd),
                                               _lib.ptr(wl.noise_d), None, wl.flags, None, 0, _lib.ptr(lmll), None, None,
                                               _lib.ptr(linfo), _lib.ptr(lws), lws.numel(), B, stream))
     l1.record()

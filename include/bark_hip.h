@@ -13,7 +13,12 @@
  *    (thread-local).  The library never aborts and never frees/retains caller buffers.
  *  - `*_hip` entry points take DEVICE pointers (e.g. torch `tensor.data_ptr()`) and a
  *    `hipStream_t` passed as `void*` (NULL = default stream).  They only enqueue work:
- *    no allocation, no host synchronisation, so they are hipGraph-capturable.
+ *    no allocation, no host synchronisation, so they are hipGraph-capturable (after one
+ *    un-captured call with the same context, which creates its helper streams and events).
+ *  - entry points that walk trees or fork helper streams take a `bark_ctx*` first: the per-device context that owns
+ *    those streams/events, a scratch buffer and the categorical-fault flag.  The library is re-entrant per context:
+ *    host threads that use one context (and one stream) each share no mutable state (SURVEY §8b Ownership /
+ *    Threading; the reference's callers are single-threaded Python, bark_sampler.py / tree_gps.py).
  *  - `*_pack*` entry points are HOST functions on host pointers (format conversion only).
  *  - all matrices are row-major float64; feature matrices X are (N, d) row-major float64.
  */
@@ -27,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BARK_HIP_VERSION 100 /* 0.1.0 */
+#define BARK_HIP_VERSION 200 /* 0.2.0: per-device context (bark_ctx) */
 
 enum {
     BARK_OK = 0,
@@ -49,6 +54,24 @@ enum {
 int bark_version(void);
 /* Last error message of the calling thread ("" if none).  Pointer valid until the next call. */
 const char *bark_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Context — replaces nothing in the reference (pure functions on numpy arrays, forest.py:58-111); it is where the
+ * state a GPU implementation needs between calls lives instead of in process globals.
+ * ------------------------------------------------------------------------------------- */
+typedef struct bark_ctx bark_ctx;
+/* One context per (host thread, device).  Does not change the current device. */
+int bark_ctx_create(int device, bark_ctx **out);
+/* Frees the helper streams, events, scratch and flag.  Synchronise the streams used with the context first. */
+void bark_ctx_destroy(bark_ctx *ctx);
+/* Grow-only, 256-byte aligned device scratch owned by the context (the `workspace` arguments below may point into
+ * it, or at any caller-owned device buffer).  *ptr_out stays valid until a later call asks for more bytes. */
+int bark_ctx_workspace(bark_ctx *ctx, size_t bytes, void **ptr_out);
+size_t bark_ctx_workspace_bytes(const bark_ctx *ctx);
+/* Reads and clears the categorical-fault flag (synchronises `stream`).  *cat_fault_out != 0: a leaf walk enqueued with
+ * this context evaluated a categorical split on a NaN / inf / negative value, where the reference raises inside
+ * `1 << int(x)` (forest.py:38).  The MLL / posterior entry points report the same condition as info_out[b] = -1. */
+int bark_ctx_status(bark_ctx *ctx, void *stream, int32_t *cat_fault_out);
 
 /* ---------------------------------------------------------------------------------------
  * Forest container  (forest.py:8-19 NODE_RECORD_DTYPE: packed 26-byte records)
@@ -83,8 +106,8 @@ int bark_forest_pack(const void *nodes26, const int64_t *feat_types, int64_t d, 
  * ------------------------------------------------------------------------------------- */
 /* (N, m) uint32 leaf NODE indices for each of the B forests: out is (B, N, m) uint32, C order —
  * bit-identical to pass_through_forest(nodes[b], X, feat_types). */
-int bark_leaf_indices_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
-                          uint32_t *out, void *stream);
+int bark_leaf_indices_hip(bark_ctx *ctx, const void *packed, const bark_pack_info *info, const double *X, int64_t N,
+                          int64_t d, uint32_t *out, void *stream);
 
 /* Leaf codes consumed by the Gram kernels: out is (B, W, Npad) uint32, W = bark_leaf_words(info),
  * Npad = bark_leaf_npad(N), point index fastest.  Two encodings, chosen from `info` alone
@@ -98,8 +121,15 @@ enum { BARK_LEAF_BYTES = 0, BARK_LEAF_BITS = 1 };
 int64_t bark_leaf_npad(int64_t N);
 int bark_leaf_encoding(const bark_pack_info *info);
 int64_t bark_leaf_words(const bark_pack_info *info);
-int bark_leaf_codes_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
-                        uint32_t *out, void *stream);
+int bark_leaf_codes_hip(bark_ctx *ctx, const void *packed, const bark_pack_info *info, const double *X, int64_t N,
+                        int64_t d, uint32_t *out, void *stream);
+
+/* One-hot leaf vectors — forest.py:70-75 get_leaf_vectors: out[i * ldo + c] = value if leaves[i * ldl] == ids[c] else 0
+ * (`np.equal(leaves[:, None], all_leaves[None, :])`, optionally scaled as bark_sampler.py:233-236 does).  leaves: leaf
+ * node indices of one tree (element stride ldl, e.g. a column of bark_leaf_indices_hip's output); ids: the r distinct
+ * reached leaves in ascending order (np.unique on the host: N * 4 bytes). */
+int bark_onehot_match_hip(const uint32_t *leaves, int64_t N, int64_t ldl, const uint32_t *ids, int64_t r, double value,
+                          double *out, int64_t ldo, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Gram matrix   — forest.py:78-111 (forest_gram_matrix / batched_forest_gram_matrix / _no_null)
@@ -135,7 +165,8 @@ int bark_gram_from_leaves_hip(const uint32_t *leaf1, int64_t N, const uint32_t *
  *
  * workspace: device buffer of at least bark_mll_workspace_bytes(N, C, m, Bc) bytes, where Bc
  * (1 <= Bc <= B) is the number of forests resident / factorised concurrently; B is processed in chunks of Bc.
- * info_out (device, B int32): 0, or 1-based index of the first non-positive pivot (not PD).
+ * info_out (device, B int32): 0, or 1-based index of the first non-positive pivot (not PD), or -1 when a leaf walk
+ * of the call met an invalid categorical value (see bark_ctx_status).
  * ------------------------------------------------------------------------------------- */
 size_t bark_mll_workspace_bytes(int64_t N, int64_t C, int64_t m, int64_t Bc);
 
@@ -151,7 +182,8 @@ typedef struct {
     double solve_flops; /* fp64 flops executed by the solve_kernel launches */
 } bark_mll_timing;
 
-int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, /* forests (device / host info) */
+int bark_mll_batched_hip(bark_ctx *ctx,
+                         const void *packed, const bark_pack_info *info, /* forests (device / host info) */
                          const double *X, int64_t N, int64_t d,         /* training inputs (device) */
                          const double *y,                               /* (N,) targets (device) */
                          const double *noise, const double *scale,      /* (B,) device; scale may be NULL */
@@ -181,7 +213,7 @@ int bark_mll_batched_hip(const void *packed, const bark_pack_info *info, /* fore
  * Pass C candidates (+ mu_out, var_out (B, C), scale, BARK_MLL_INCLUDE_SCALE); at most 64 trees.
  * ------------------------------------------------------------------------------------- */
 size_t bark_mll_leafspace_workspace_bytes(int64_t N, int64_t max_bits, int64_t m, int64_t Bc, int64_t C);
-int bark_mll_leafspace_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
+int bark_mll_leafspace_hip(bark_ctx *ctx, const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
                            const double *y, const double *noise, const double *scale, int flags, const double *cand,
                            int64_t C, double *mll_out, double *mu_out, double *var_out, int32_t *info_out,
                            void *workspace, size_t workspace_bytes, int64_t Bc, void *stream);
@@ -193,7 +225,7 @@ int bark_mll_leafspace_hip(const void *packed, const bark_pack_info *info, const
  * (mll in the convention selected by `flags`, as above).  kinv_out: (B, N, N); kinv_y_out: (B, N) or NULL.
  * Cost: the R x R sweep with an identity right-hand side + N R m + N^2 m gathered adds. */
 size_t bark_kernel_inverse_leafspace_workspace_bytes(int64_t N, int64_t max_bits, int64_t m, int64_t Bc);
-int bark_kernel_inverse_leafspace_hip(const void *packed, const bark_pack_info *info, const double *X, int64_t N,
+int bark_kernel_inverse_leafspace_hip(bark_ctx *ctx, const void *packed, const bark_pack_info *info, const double *X, int64_t N,
                                       int64_t d, const double *y, const double *noise, const double *scale, int flags,
                                       double *mll_out, double *kinv_out, double *kinv_y_out, int32_t *info_out,
                                       void *workspace, size_t workspace_bytes, int64_t Bc, void *stream);
@@ -210,6 +242,10 @@ size_t bark_lowrank_workspace_bytes(int64_t N, int64_t r);
 int bark_lowrank_update_hip(const double *K_inv, int64_t N, const double *U, int64_t r, int subtract, int symmetric,
                             double *K_out, double *logabsdet_out, void *workspace, size_t workspace_bytes,
                             void *stream);
+/* *singular_out (HOST) = 1-based column of the first exactly-zero pivot of (mul I + U' K_inv U) met by the last
+ * bark_lowrank_update_hip / swap evaluation that used `workspace` with this (N, r), or 0.  Synchronises `stream`.
+ * The reference's np.linalg.solve / slogdet raise LinAlgError there (quick_inverse.py:19,31). */
+int bark_lowrank_status_hip(void *workspace, int64_t N, int64_t r, int32_t *singular_out, void *stream);
 
 /* Fused tree swap for the sampler's per-tree step (bark_sampler.py:233-257): the reference chains
  * subtract(U_old) -> add(U_new) -> mll on K_inv (about nine passes over the N x N matrix) before it can
@@ -232,7 +268,7 @@ int bark_lowrank_swap_apply_hip(const double *K_inv, int64_t N, int64_t r, void 
  * workspace (>= bark_tree_swap_workspace_bytes(N, info->max_bits)) begins with the swap_eval layout:
  * bark_lowrank_swap_apply_hip(K_inv, N, info->max_bits, workspace, K_out, stream) commits the proposal. */
 size_t bark_tree_swap_workspace_bytes(int64_t N, int64_t r);
-int bark_tree_swap_eval_hip(const double *K_inv, int64_t N, const void *packed, const bark_pack_info *info,
+int bark_tree_swap_eval_hip(bark_ctx *ctx, const double *K_inv, int64_t N, const void *packed, const bark_pack_info *info,
                             const double *X, int64_t d, int64_t r_old, double s, const double *y, double *scalars_out,
                             void *workspace, size_t workspace_bytes, void *stream);
 
@@ -244,15 +280,49 @@ int bark_tree_swap_eval_hip(const double *K_inv, int64_t N, const void *packed, 
  * for all chains); otherwise each chain's single-chain sequence runs on its own stream forked from `stream`.
  * ..._apply_chains: K_inv[b] is rewritten in place for every b with accept[b] != 0 (HOST int32 array). */
 size_t bark_tree_swap_chains_workspace_bytes(int64_t N, int64_t r, int64_t nc, size_t *chain_stride_bytes);
-int bark_tree_swap_eval_chains_hip(const double *K_inv, int64_t N, int64_t nc, const void *packed,
+int bark_tree_swap_eval_chains_hip(bark_ctx *ctx, const double *K_inv, int64_t N, int64_t nc, const void *packed,
                                    const bark_pack_info *info, const double *X, int64_t d, const int64_t *r_old,
                                    const double *s, const double *y, double *scalars_out, void *workspace,
                                    size_t workspace_bytes, void *stream);
 int bark_lowrank_swap_apply_chains_hip(double *K_inv, int64_t N, int64_t nc, int64_t r, const int32_t *accept,
                                        void *workspace, size_t workspace_bytes, void *stream);
 
+/* One sweep over the trees of nc chains with the Metropolis decision taken on the DEVICE — the per-tree loop of
+ * bark_sampler.py:233-264 without a host round trip per tree.  Step t < n_steps swaps one tree per chain:
+ *   packed + packed_offsets[t] (bytes, HOST array), infos[t] (HOST array): wire format of the step's nc pairs
+ *                                          [old tree, new tree]  (bark_forest_pack with B = nc, m = 2)
+ *   r_old[t * nc + b] (HOST)               leaves of chain b's old tree;  s[b] (HOST) = sqrt(scale_b / m)
+ *   log_q_prior, log_u (DEVICE, (n_steps, nc))   proposal ratio and log of the uniform draw of bark_sampler.py:258
+ * Per step: evaluate (as bark_tree_swap_eval_chains_hip), accept iff log_u <= min(log_q_prior + 0.5 (dquad - dlogdet), 0),
+ * rewrite K_inv[b] of the accepted chains.  state (DEVICE, (nc, 2)): y'K^-1 y and log|K| per chain, updated in place.
+ * accept_out (DEVICE int32, (n_steps, nc)): 1 accepted, 0 rejected, -1 singular r x r system (the reference raises
+ * LinAlgError).  Nothing synchronises: the host reads accept_out and state once per sweep.
+ * workspace >= bark_tree_swap_chains_workspace_bytes(N, r_max, nc, NULL) + 16 * nc bytes, r_max = max_t infos[t].max_bits. */
+int bark_tree_sweep_chains_hip(bark_ctx *ctx, double *K_inv, int64_t N, int64_t nc, int64_t n_steps, const void *packed,
+                               const int64_t *packed_offsets, const bark_pack_info *infos, const double *X, int64_t d,
+                               const int64_t *r_old, const double *s, const double *y, const double *log_q_prior,
+                               const double *log_u, double *state, int32_t *accept_out, void *workspace,
+                               size_t workspace_bytes, void *stream);
+
 /* quick_inverse.py:37-38  mll(K_inv, K_logdet, y) = 0.5 * (-y' K_inv y - K_logdet), on device. */
 int bark_quadform_hip(const double *K_inv, const double *y, int64_t N, double *out, void *stream);
+/* out[b] = alpha * sum_i A[b * lda + i] * y[i] + beta * c[b] for b < B (c may be NULL) — e.g. log|K_s| =
+ * -(y' K_s^-1 y) - 2 mll from the rows K_s^-1 y of the inverse export (opt_model.py:101) and the MLL vector. */
+int bark_rowdot_hip(const double *A, int64_t B, int64_t N, int64_t lda, const double *y, double alpha, const double *c,
+                    double beta, double *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Mixture of Gaussians over forest samples — tree_gps.py:116-131 (mixture_of_gaussians_as_normal):
+ *   E[Y] = mean_b mu_b ;  Var[Y] = mean_b (var_b + mu_b^2) - E[Y]^2
+ * in two steps so that shards of samples on several GPUs combine with one all-reduce(sum) of `partial`:
+ *   partial (2, C): [sum_b mu_b, sum_b (var_b + mu_b^2)] over the B local samples; finish divides by the global count.
+ * ------------------------------------------------------------------------------------- */
+int bark_mixture_partial_hip(const double *mu, const double *var, int64_t B, int64_t C, double *partial, void *stream);
+int bark_mixture_finish_hip(const double *partial, double total, int64_t C, double *mean, double *var, void *stream);
+
+/* Strided device-to-device copy of a rows x cols float64 block (hipMemcpy2DAsync): assembling [U_old U_new] from two
+ * leaf-vector matrices (bark_sampler.py:233-236) without host arithmetic on device data. */
+int bark_copy2d_hip(double *dst, int64_t ldd, const double *src, int64_t lds, int64_t rows, int64_t cols, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,206 @@
+"""Boundary behaviour of the C ABI on the GPU: per-thread contexts (two host threads on two streams), hipGraph
+capture of the sweep, the device-side Metropolis sweep of the sampler step, and the error paths the reference has
+(singular low-rank systems, invalid categorical values met by a walk)."""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    assert torch.cuda.is_available()
+    import bark_amd.fitting as fit
+    import bark_amd.forest as bf
+    from bark_amd import _lib, synthetic
+    from oracle import oracle as orc
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.torch, ns.fit, ns.bf, ns.lib, ns.syn, ns.orc = torch, fit, bf, _lib, synthetic, orc
+    return ns
+
+
+def test_context_lifecycle_and_argument_checks(env):
+    L, lib = env.lib, env.lib.lib()
+    h = ctypes.c_void_p()
+    L.check(lib.bark_ctx_create(0, ctypes.byref(h)))
+    p1, p2 = ctypes.c_void_p(), ctypes.c_void_p()
+    L.check(lib.bark_ctx_workspace(h, 1 << 20, ctypes.byref(p1)))
+    L.check(lib.bark_ctx_workspace(h, 1 << 16, ctypes.byref(p2)))  # smaller request: same buffer
+    assert p1.value == p2.value and p1.value % 256 == 0 and lib.bark_ctx_workspace_bytes(h) == 1 << 20
+    L.check(lib.bark_ctx_workspace(h, 1 << 22, ctypes.byref(p2)))
+    assert lib.bark_ctx_workspace_bytes(h) == 1 << 22
+    flag = ctypes.c_int32(7)
+    L.check(lib.bark_ctx_status(h, None, ctypes.byref(flag)))
+    assert flag.value == 0
+    lib.bark_ctx_destroy(h)
+    assert lib.bark_ctx_create(99, ctypes.byref(h)) != 0 and b"device" in lib.bark_last_error()
+    # an entry point without a context refuses to run
+    X = env.torch.zeros((4, 2), dtype=env.torch.float64, device="cuda")
+    out = env.torch.zeros((1, 4, 1), dtype=env.torch.int32, device="cuda")
+    info = L.PackInfo()
+    rc = lib.bark_leaf_indices_hip(None, L.ptr(X), ctypes.byref(info), L.ptr(X), 4, 2, L.ptr(out), None)
+    assert rc == L.BARK_ERR_ARG and b"bark_ctx" in lib.bark_last_error()
+
+
+def test_two_host_threads_on_two_streams(env):
+    """Each thread has its own context (scratch, helper stream, events) and its own stream: results are bit-identical
+    to the serial ones however the launches interleave."""
+    torch, fit, syn = env.torch, env.fit, env.syn
+    X, y, bounds, ft = syn.mixed_problem(900, seed=11)
+    jobs = []
+    for k in range(2):
+        F = syn.sample_prior_forests(24, 50, bounds, ft, seed=100 + k)
+        noise = np.linspace(0.05, 0.2, 24) + 0.01 * k
+        jobs.append((F, noise))
+    serial = [fit.batched_mll(F, n, None, X, y, ft, include_scale=False, include_2pi=True) for F, n in jobs]
+    results, errors = [None, None], []
+
+    def work(k):
+        try:
+            torch.cuda.set_device(0)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                F, n = jobs[k]
+                outs = [fit.batched_mll(F, n, None, X, y, ft, include_scale=False, include_2pi=True) for _ in range(6)]
+                s.synchronize()
+            results[k] = outs
+            env.lib.release_ctx()
+        except Exception as exc:  # pragma: no cover
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    for k in range(2):
+        for out in results[k]:
+            assert np.array_equal(out, serial[k])
+
+
+def test_sweep_is_hipgraph_capturable(env):
+    """The ABI's claim: `*_hip` entry points only enqueue work (fork/join of the helper stream included), so a call can
+    be captured into a graph and replayed — what a latency-bound caller (one small matrix) wants."""
+    import bench
+
+    torch = env.torch
+    wl = bench.Workload(1024, 8, 50, 1, seed_base=1024, rank_offset=0)
+    wl.run()  # creates the context's helper stream / events and sets the LDS attributes outside the capture
+    torch.cuda.synchronize()
+    eager = wl.mll_d.clone()
+    g = torch.cuda.CUDAGraph()
+    wl.mll_d.zero_()
+    with torch.cuda.graph(g):
+        wl.stream = env.lib.stream_ptr()  # the capture stream
+        wl.run()
+    wl.mll_d.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert bool((wl.mll_d == eager).all()) and int(wl.info_d.abs().max().item()) == 0
+    # a larger batch through the non-split path as well
+    wl2 = bench.Workload(700, 8, 50, 64, seed_base=700, rank_offset=0)
+    wl2.run()
+    torch.cuda.synchronize()
+    eager2 = wl2.mll_d.clone()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        wl2.stream = env.lib.stream_ptr()
+        wl2.run()
+    wl2.mll_d.zero_()
+    g2.replay()
+    torch.cuda.synchronize()
+    assert bool((wl2.mll_d == eager2).all())
+
+
+@pytest.mark.parametrize("N", [300, 301])
+def test_device_side_metropolis_sweep_matches_host_loop(env, N):
+    """ChainBatch.sweep_trees (decision on the device, one read-back per sweep) against the per-tree host loop of
+    bark_sampler.py:233-264 driven through propose_trees / accept with the same proposals and uniform draws.
+    N even: all chains in one launch sequence; N odd: one stream per chain."""
+    fit, syn = env.fit, env.syn
+    nc, m = 3, 8
+    X, y, bounds, ft = syn.mixed_problem(N, seed=5)
+    cur = syn.sample_prior_forests(nc, m, bounds, ft, seed=50)
+    prop = syn.sample_prior_forests(nc, m, bounds, ft, seed=500)  # proposal for tree t of chain b: prop[b, t]
+    noise, scale = np.array([0.1, 0.07, 0.2]), np.array([1.0, 0.8, 1.2])
+    rng = np.random.default_rng(9)
+    log_q = rng.normal(0.0, 0.5, size=(nc, m))
+    log_u = np.log(rng.uniform(size=(nc, m)))
+    host = fit.ChainBatch.from_forests(cur, noise, scale, X, y, ft)
+    want_mask = np.zeros((nc, m), dtype=bool)
+    for t in range(m):
+        before = host.mll.copy()
+        vals = host.propose_trees(cur[:, t], prop[:, t], X, ft, scale, m)
+        want_mask[:, t] = log_u[:, t] <= np.minimum(log_q[:, t] + (vals - before), 0.0)
+        host.accept(want_mask[:, t])
+    dev = fit.ChainBatch.from_forests(cur, noise, scale, X, y, ft)
+    mask = dev.sweep_trees(cur, prop, log_q, log_u, X, ft, scale, m)
+    assert mask.shape == (nc, m) and np.array_equal(mask, want_mask)
+    assert 0 < mask.sum() < mask.size  # both branches exercised
+    assert np.allclose(dev.mll, host.mll, rtol=1e-12, atol=1e-10)
+    assert bool((dev.K_inv == host.K_inv).all())  # same kernels, same order: identical bits
+    # and the end state against a full recomputation by the oracle
+    final = cur.copy()
+    final[mask] = prop[mask]
+    want = env.orc.batched_mll(final, noise, scale, X, y, ft, include_scale=True, include_2pi=False)
+    assert np.allclose(dev.mll, want, rtol=1e-9, atol=1e-8)
+
+
+def test_singular_low_rank_system_raises_linalgerror(env):
+    """quick_inverse.py:19,31: np.linalg.solve / slogdet raise on a singular (mul I + U' K_inv U)."""
+    from bark_amd.fitting import quick_inverse as qi
+
+    K_inv = np.eye(6)
+    U = np.zeros((6, 1))
+    U[0, 0] = 1.0  # subtract: -1 + e0' I e0 = 0
+    with pytest.raises(np.linalg.LinAlgError):
+        qi.low_rank_inv_update(K_inv, U, subtract=True)
+    with pytest.raises(np.linalg.LinAlgError):
+        qi.low_rank_det_update(K_inv, U, 0.0, subtract=True)
+    with pytest.raises(np.linalg.LinAlgError):
+        env.orc.low_rank_inv_update(K_inv, U, subtract=True)  # the oracle (numpy) behaves the same way
+    out = qi.low_rank_inv_update(K_inv, U, subtract=False)
+    assert np.allclose(out, env.orc.low_rank_inv_update(K_inv, U, subtract=False))
+
+
+def test_invalid_category_raises_only_where_a_walk_evaluates_it(env):
+    """forest.py:37-39: `1 << int(x)` raises for NaN / inf / negative x — but only when a walk reaches a categorical
+    split with that value.  A bad value on a point whose walks never test the feature passes, as in the reference."""
+    bf, syn = env.bf, env.syn
+    ft = np.array([2, 0])  # feature 0 continuous, feature 1 categorical
+    forest = bf.create_empty_forest(1, 8)
+    # root: x0 <= 0.5 -> left = leaf 1 ; right = node 2: categorical split on feature 1 (mask 0b0101) -> leaves 3, 4
+    forest[0, 0] = (0, 0, 0.5, 1, 2, 0xFFFFFFFF, 0, 1)
+    forest[0, 1] = (1, 0, 0, 0, 0, 0, 1, 1)
+    forest[0, 2] = (0, 1, float(0b0101), 3, 4, 0, 1, 1)
+    forest[0, 3] = (1, 0, 0, 0, 0, 2, 2, 1)
+    forest[0, 4] = (1, 0, 0, 0, 0, 2, 2, 1)
+    X = np.array([[0.2, 1.0], [0.9, 0.0], [0.9, 1.0], [0.9, 2.0]])
+    assert np.array_equal(bf.pass_through_forest(forest, X, ft)[:, 0], [1, 3, 4, 3])
+    assert np.array_equal(bf.pass_through_forest(forest, X, ft), env.orc.pass_through_forest(forest, X, ft))
+    for bad in (np.nan, -1.0, np.inf, -np.inf):
+        ok = X.copy()
+        ok[0, 1] = bad  # point 0 goes left at the root: the categorical split is never evaluated for it
+        assert np.array_equal(bf.pass_through_forest(forest, ok, ft)[:, 0], [1, 3, 4, 3])
+        assert np.array_equal(env.orc.pass_through_forest(forest, ok, ft)[:, 0], [1, 3, 4, 3])
+        hit = X.copy()
+        hit[2, 1] = bad
+        with pytest.raises(ValueError):
+            bf.pass_through_forest(forest, hit, ft)
+        with pytest.raises(ValueError):
+            bf.forest_gram_matrix(forest, hit, hit, ft)
+        with pytest.raises(ValueError):
+            env.fit.batched_mll(forest[None], [0.1], [1.0], hit, np.arange(4.0), ft, include_scale=True, include_2pi=False)
+        # the fault flag does not leak into the next call
+        assert np.array_equal(bf.pass_through_forest(forest, X, ft)[:, 0], [1, 3, 4, 3])
+    assert np.array_equal(bf.pass_through_forest(forest, np.array([[0.9, -0.5]]), ft)[:, 0], [3])  # int(-0.5) == 0

@@ -698,14 +698,41 @@ def test_argument_validation_across_the_api(B):
         state.propose_tree(F[0][0], F[1][0], X[:50], ft, 1.0, 7)
     with pytest.raises(ValueError, match="N rows"):
         state.propose(np.ones((50, 2)), np.ones((90, 2)))
-    rng = np.random.default_rng(0)
-    bushy = B.syn.full_binary_forest(2, 12, 6, rng, node_limit=127)  # 64 leaves each: 128 columns in one swap
-    Xc = rng.uniform(size=(90, 12))
-    st2 = B.fit.ChainState.from_forest(bushy, 0.1, 1.0, Xc, y, np.full(12, 2))
-    with pytest.raises(ValueError, match="64"):
-        st2.propose_tree(bushy[0], bushy[1], Xc, np.full(12, 2), 1.0, 2)
     with pytest.raises(RuntimeError):
-        st2.accept()
+        state.accept()
+
+
+def test_tree_swap_with_more_than_64_leaves(B):
+    """Tree pairs beyond the 64-column limit of one fused update (the default container allows 50 leaves per tree,
+    tree_proposals.py:46-58): (a) structurally > 64 leaves but <= 64 reached -> reached-leaf vectors in one update;
+    (b) > 64 reached -> the reference's own subtract-then-add chain (bark_sampler.py:242-255).  Both against a full
+    recomputation by the oracle, for ChainState and ChainBatch."""
+    rng = np.random.default_rng(0)
+    ft = np.full(12, 2)
+    bushy = B.syn.full_binary_forest(3, 12, 6, rng, node_limit=127)  # 64 leaves per tree
+    for N in (30, 400):  # (a) at most 30 leaves reached per tree; (b) nearly all 64 + 64
+        Xc = rng.uniform(size=(N, 12))
+        y = rng.standard_normal((N, 1))
+        cur = bushy[:2].copy()  # the chain's forest: trees 0, 1; proposal: tree 0 -> tree 2
+        st = B.fit.ChainState.from_forest(cur, 0.1, 1.3, Xc, y, ft)
+        got = st.propose_tree(cur[0], bushy[2], Xc, ft, 1.3, 2)
+        new_forest = np.stack([bushy[2], bushy[1]])
+        want = B.orc.batched_mll(new_forest[None], [0.1], [1.3], Xc, y, ft, include_scale=True, include_2pi=False)[0]
+        assert np.isclose(got, want, rtol=1e-9, atol=1e-8), (N, got, want)
+        st.accept()
+        K = 1.3 * B.orc.forest_gram_matrix(new_forest, Xc, Xc, ft) + (1e-6 + 0.1) * np.eye(N)
+        assert np.allclose(st.K_inv.cpu().numpy(), np.linalg.inv(K), rtol=1e-7, atol=1e-9)
+        assert np.isclose(st.mll, want, rtol=1e-9, atol=1e-8)
+        # two chains, one of them with the bushy pair
+        cb = B.fit.ChainBatch.from_forests(np.stack([cur, cur]), [0.1, 0.2], [1.3, 0.9], Xc, y, ft)
+        vals = cb.propose_trees(np.stack([cur[0], cur[1]]), np.stack([bushy[2], bushy[2]]), Xc, ft, [1.3, 0.9], 2)
+        f1 = np.stack([cur[0], bushy[2]])
+        want2 = [want, B.orc.batched_mll(f1[None], [0.2], [0.9], Xc, y, ft, include_scale=True, include_2pi=False)[0]]
+        assert np.allclose(vals, want2, rtol=1e-9, atol=1e-8)
+        cb.accept([True, False])
+        assert np.allclose(cb.mll, [want, B.orc.batched_mll(cur[None], [0.2], [0.9], Xc, y, ft, include_scale=True,
+                                                            include_2pi=False)[0]], rtol=1e-9, atol=1e-8)
+        assert np.allclose(cb.K_inv[0].cpu().numpy(), np.linalg.inv(K), rtol=1e-7, atol=1e-9)
 
 
 def test_torch_tensors_stay_on_device(B):

@@ -71,13 +71,15 @@ def main():
             if hasattr(h, name):
                 fn = getattr(h, name)
                 fn.restype, fn.argtypes = res, args
+        hctx = ctypes.c_void_p()
+        assert h.bark_ctx_create(dev.index, ctypes.byref(hctx)) == 0
         out = torch.empty(B, dtype=torch.float64, device=dev)
         info = torch.empty(B, dtype=torch.int32, device=dev)
         mu = torch.empty((B, C), dtype=torch.float64, device=dev) if C else None
         var = torch.empty((B, C), dtype=torch.float64, device=dev) if C else None
 
-        def run(h=h, ws=ws, out=out, info=info, mu=mu, var=var):
-            rc = h.bark_mll_batched_hip(_lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(yd), _lib.ptr(nd),
+        def run(h=h, hctx=hctx, ws=ws, out=out, info=info, mu=mu, var=var):
+            rc = h.bark_mll_batched_hip(hctx, _lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(yd), _lib.ptr(nd),
                                         _lib.ptr(sd), None, flags, _lib.ptr(cd), C, _lib.ptr(out), _lib.ptr(mu), _lib.ptr(var),
                                         None, _lib.ptr(info), _lib.ptr(ws), ws.numel(), B, None, _lib.stream_ptr())
             assert rc == 0, h.bark_last_error()

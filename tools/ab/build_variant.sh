@@ -12,7 +12,7 @@ if [ -n "$GIT_REV" ]; then
   src=$tmp/bark_amd/csrc
 fi
 objs=""
-for f in pack.cpp traverse.hip gram.hip chol.hip lowrank.hip leafspace.hip; do
+for f in $(cd $src && ls *.cpp *.hip); do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function "$@" -x hip -c $src/$f -o /tmp/abv_${name}_$f.o &
   objs="$objs /tmp/abv_${name}_$f.o"
 done
