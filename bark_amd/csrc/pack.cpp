@@ -54,6 +54,7 @@ struct Scratch {
     std::vector<uint8_t> colour; // 0 white, 1 on the DFS stack, 2 finished
     std::vector<uint32_t> stack_node;
     std::vector<uint8_t> stack_phase;
+    std::vector<int32_t> height;  // edges to the farthest leaf below a finished node
 };
 
 struct TreeStats {
@@ -68,7 +69,8 @@ int pack_tree(const uint8_t *tree, int64_t L, const int64_t *feat_types, int64_t
     s.colour.assign((size_t)L, 0);
     s.stack_node.clear();
     s.stack_phase.clear();
-    int64_t n_nodes = 0, n_leaves = 0, max_depth = 0;
+    s.height.assign((size_t)L, 0);
+    int64_t n_nodes = 0, n_leaves = 0;
 
     auto discover = [&](uint32_t orig) -> int {
         if (out && n_nodes >= cap) return 1;
@@ -76,8 +78,6 @@ int pack_tree(const uint8_t *tree, int64_t L, const int64_t *feat_types, int64_t
         s.colour[orig] = 1;
         s.stack_node.push_back(orig);
         s.stack_phase.push_back(0);
-        int64_t depth = (int64_t)s.stack_node.size() - 1;
-        if (depth > max_depth) max_depth = depth;
         return 0;
     };
     if (discover(0)) return fail(BARK_ERR_ARG, "bark_forest_pack: info does not match forest");
@@ -141,13 +141,18 @@ int pack_tree(const uint8_t *tree, int64_t L, const int64_t *feat_types, int64_t
             if (slot) slot[2 + phase] = (uint32_t)s.cidx[child];
             continue;
         }
+        // The walk bound is the LONGEST root-to-leaf path.  The reference just follows child pointers, so a node
+        // that two parents share (not a tree, but walkable) may sit deeper on one path than where the DFS first met
+        // it: heights are taken bottom-up from the finished children, not from the discovery depth.
+        const int32_t hl = s.height[n.left], hr = s.height[n.right];
+        s.height[orig] = 1 + (hl > hr ? hl : hr);
         s.colour[orig] = 2;
         s.stack_node.pop_back();
         s.stack_phase.pop_back();
     }
     stats->nodes = n_nodes;
     stats->leaves = n_leaves;
-    stats->depth = max_depth;
+    stats->depth = s.height[0];
     return BARK_OK;
 }
 

@@ -204,3 +204,22 @@ def test_invalid_category_raises_only_where_a_walk_evaluates_it(env):
         # the fault flag does not leak into the next call
         assert np.array_equal(bf.pass_through_forest(forest, X, ft)[:, 0], [1, 3, 4, 3])
     assert np.array_equal(bf.pass_through_forest(forest, np.array([[0.9, -0.5]]), ft)[:, 0], [3])  # int(-0.5) == 0
+
+
+def test_node_with_two_parents_walks_like_the_reference(env):
+    """The device walk is bounded by the packer's max_depth: with a shared node discovered first on a shallow path the
+    bound must still cover the deep one (longest path), otherwise a point ends on an internal node."""
+    bf = env.bf
+    nodes = bf.create_empty_forest(1, 8)
+    nodes[0, 0] = (0, 0, 0.5, 1, 2, 0xFFFFFFFF, 0, 1)
+    nodes[0, 1] = (0, 0, 0.25, 3, 7, 0, 1, 1)
+    nodes[0, 2] = (0, 0, 0.75, 4, 7, 0, 1, 1)
+    nodes[0, 4] = (0, 0, 0.6, 3, 7, 2, 2, 1)
+    nodes[0, 3] = (0, 0, 0.1, 5, 6, 1, 2, 1)
+    for leaf in (5, 6, 7):
+        nodes[0, leaf] = (1, 0, 0, 0, 0, 0, 3, 1)
+    ft = np.array([2], dtype=np.int64)
+    X = np.array([[0.55], [0.2], [0.05], [0.9], [0.3]])
+    want = env.orc.pass_through_forest(nodes, X, ft)
+    assert np.array_equal(bf.pass_through_forest(nodes, X, ft), want)
+    assert np.array_equal(bf.forest_gram_matrix(nodes, X, X, ft), env.orc.forest_gram_matrix(nodes, X, X, ft))

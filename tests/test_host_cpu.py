@@ -240,3 +240,28 @@ def test_committed_bench_line_follows_the_contract():
     assert roof["traffic"] is None or roof["traffic"] > 0
     cpu = r["cpu_baseline"]
     assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
+
+
+def test_packer_walk_bound_is_the_longest_path_when_a_node_has_two_parents():
+    """A node shared by two parents is not a tree, but the reference's walk (forest.py:28-47) just follows the child
+    pointers.  The packer's max_depth bounds the device walk, so it must be the longest root-to-leaf path even when
+    the shared node is first discovered on a shallower one."""
+    import ctypes
+
+    from bark_amd import _lib
+
+    nodes = bf.create_empty_forest(1, 8)
+    # root(0): left -> 1 (shallow path to the shared node 3), right -> 2 -> 4 -> 3 (deep path);  3: split -> leaves 5, 6
+    nodes[0, 0] = (0, 0, 0.5, 1, 2, 0xFFFFFFFF, 0, 1)
+    nodes[0, 1] = (0, 0, 0.25, 3, 7, 0, 1, 1)
+    nodes[0, 2] = (0, 0, 0.75, 4, 7, 0, 1, 1)
+    nodes[0, 4] = (0, 0, 0.6, 3, 7, 2, 2, 1)
+    nodes[0, 3] = (0, 0, 0.1, 5, 6, 1, 2, 1)
+    for leaf in (5, 6, 7):
+        nodes[0, leaf] = (1, 0, 0, 0, 0, 0, 3, 1)
+    ft = np.array([2], dtype=np.int64)
+    info = _lib.PackInfo()
+    _lib.check(_lib.lib().bark_forest_pack_info(_lib.ptr(nodes), 1, 1, 8, _lib.ptr(ft), 1, ctypes.byref(info)))
+    assert info.max_depth == 4  # 0 -> 2 -> 4 -> 3 -> leaf
+    # the oracle follows the pointers like the reference: x = 0.55 takes the deep path and ends on leaf 6
+    assert orc.pass_through_forest(nodes, np.array([[0.55], [0.2], [0.05]]), ft)[:, 0].tolist() == [6, 6, 5]
