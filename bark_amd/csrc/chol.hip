@@ -372,31 +372,72 @@ __device__ __forceinline__ double row_bcast_f64(double v) {
     return __hiloint2double(hi, lo);
 }
 
-// Elimination step K of factor16 on [D | I] (lane (g, c) holds rows g + 4v of column c in e[v] / f[v]).
-// Row K lives in register K >> 2 of lane group K & 3.  The multipliers D[K][r] / d for the lane's own rows are
-// read as D[r][K] (the trailing block stays symmetric): same 16-lane row, position K -> a DPP broadcast; only
-// the pivot row's entries D[K][c], I[K][c] cross lane groups (ds_bpermute), the pivot itself is a readlane.
-template <int K>
-__device__ __forceinline__ void pivot16(double (&e)[4], double (&f)[4], int c, int g, int base_index, int &bad) {
-    constexpr int kv = K >> 2, kl = (K & 3) * 16;
-    const double lc = __shfl(e[kv], kl + c);  // D[K][c]
-    const double rc = __shfl(f[kv], kl + c);  // I[K][c]
-    double d = readlane_f64(e[kv], kl + K);
-    if (!(d > 0.0)) {  // not positive definite / NaN: flag once, continue finite
-        if (!bad) bad = base_index + K + 1;
-        d = 1.0;
-    }
-    const double rd = recip_pos(d);
+// Four elimination steps of factor16 at once (pivots K0 = 4Q .. K0+3) on [D | I]; lane (g, c) holds rows g + 4v of
+// column c in e[v] / f[v].  The four pivot rows of block Q are register Q of the four lane groups, so
+//   * their entries at this lane's column cross lane groups once per BLOCK (8 ds_bpermute, issued first) instead of
+//     once per pivot,
+//   * the 4 x 4 diagonal block comes by v_readlane (wave-uniform) and every lane repeats its small LDL factorisation
+//     (4 reciprocals on the dependent chain instead of 16 pivot-to-pivot round trips),
+//   * the multipliers of the lane's own rows are read from the pivot COLUMNS (the trailing block is symmetric) by DPP
+//     row broadcasts and pushed through the block's unit-lower factor, then applied as one rank-4 update.
+// The per-element operation order is that of four single-pivot steps.
+template <int Q>
+__device__ __forceinline__ void block4(double (&e)[4], double (&f)[4], int c, int g, int base_index, int &bad) {
+    constexpr int K0 = 4 * Q;
+    double A0 = __shfl(e[Q], 0 * 16 + c), A1 = __shfl(e[Q], 1 * 16 + c), A2 = __shfl(e[Q], 2 * 16 + c),
+           A3 = __shfl(e[Q], 3 * 16 + c);  // D[K0 + j][c]
+    double S0 = __shfl(f[Q], 0 * 16 + c), S1 = __shfl(f[Q], 1 * 16 + c), S2 = __shfl(f[Q], 2 * 16 + c),
+           S3 = __shfl(f[Q], 3 * 16 + c);  // I[K0 + j][c]
+    const double P00 = readlane_f64(e[Q], 0 * 16 + K0 + 0), P01 = readlane_f64(e[Q], 0 * 16 + K0 + 1),
+                 P02 = readlane_f64(e[Q], 0 * 16 + K0 + 2), P03 = readlane_f64(e[Q], 0 * 16 + K0 + 3),
+                 P11 = readlane_f64(e[Q], 1 * 16 + K0 + 1), P12 = readlane_f64(e[Q], 1 * 16 + K0 + 2),
+                 P13 = readlane_f64(e[Q], 1 * 16 + K0 + 3), P22 = readlane_f64(e[Q], 2 * 16 + K0 + 2),
+                 P23 = readlane_f64(e[Q], 2 * 16 + K0 + 3), P33 = readlane_f64(e[Q], 3 * 16 + K0 + 3);
+    auto pivot = [&](double d, int k) {  // not positive definite / NaN: flag once, continue finite
+        if (!(d > 0.0)) {
+            if (!bad) bad = base_index + K0 + k + 1;
+            d = 1.0;
+        }
+        return recip_pos(d);
+    };
+    const double rd0 = pivot(P00, 0);
+    const double l10 = P01 * rd0, l20 = P02 * rd0, l30 = P03 * rd0;
+    const double d1 = fma(-l10, P01, P11), t12 = fma(-l10, P02, P12), t13 = fma(-l10, P03, P13);
+    const double rd1 = pivot(d1, 1);
+    const double l21 = t12 * rd1, l31 = t13 * rd1;
+    const double d2 = fma(-l21, t12, fma(-l20, P02, P22)), t23 = fma(-l21, t13, fma(-l20, P03, P23));
+    const double rd2 = pivot(d2, 2);
+    const double l32 = t23 * rd2;
+    const double d3 = fma(-l32, t23, fma(-l31, t13, fma(-l30, P03, P33)));
+    const double rd3 = pivot(d3, 3);
+    // the block's own rows after its four steps, at this lane's column
+    A1 = fma(-l10, A0, A1);
+    A2 = fma(-l21, A1, fma(-l20, A0, A2));
+    A3 = fma(-l32, A2, fma(-l31, A1, fma(-l30, A0, A3)));
+    S1 = fma(-l10, S0, S1);
+    S2 = fma(-l21, S1, fma(-l20, S0, S2));
+    S3 = fma(-l32, S2, fma(-l31, S1, fma(-l30, S0, S3)));
+    // rows below the block: multipliers from the pivot columns, then the rank-4 update
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        const int r = g + 4 * v;
-        const double m = row_bcast_f64<K>(e[v]) * rd;  // D[r][K] / d
-        if (r > K) {
-            e[v] = fma(-m, lc, e[v]);
-            f[v] = fma(-m, rc, f[v]);
+        if (v > Q) {
+            const double a0 = row_bcast_f64<K0 + 0>(e[v]);
+            double a1 = row_bcast_f64<K0 + 1>(e[v]), a2 = row_bcast_f64<K0 + 2>(e[v]), a3 = row_bcast_f64<K0 + 3>(e[v]);
+            const double m0 = a0 * rd0;
+            a1 = fma(-m0, P01, a1);
+            const double m1 = a1 * rd1;
+            a2 = fma(-m1, t12, fma(-m0, P02, a2));
+            const double m2 = a2 * rd2;
+            a3 = fma(-m2, t23, fma(-m1, t13, fma(-m0, P03, a3)));
+            const double m3 = a3 * rd3;
+            e[v] = fma(-m3, A3, fma(-m2, A2, fma(-m1, A1, fma(-m0, A0, e[v]))));
+            f[v] = fma(-m3, S3, fma(-m2, S2, fma(-m1, S1, fma(-m0, S0, f[v]))));
         }
     }
-    if constexpr (K + 1 < SB) pivot16<K + 1>(e, f, c, g, base_index, bad);
+    // lane group j owns row K0 + j of the block
+    e[Q] = g == 0 ? A0 : g == 1 ? A1 : g == 2 ? A2 : A3;
+    f[Q] = g == 0 ? S0 : g == 1 ? S1 : g == 2 ? S2 : S3;
+    if constexpr (Q + 1 < 4) block4<Q + 1>(e, f, c, g, base_index, bad);
 }
 
 __device__ __forceinline__ void factor16(double *blk, int lane, int base_index, double &logsum, int &bad) {
@@ -407,7 +448,7 @@ __device__ __forceinline__ void factor16(double *blk, int lane, int base_index, 
         e[v] = blk[(g + 4 * v) * SB + c];
         f[v] = (g + 4 * v == c) ? 1.0 : 0.0;
     }
-    pivot16<0>(e, f, c, g, base_index, bad);
+    block4<0>(e, f, c, g, base_index, bad);
     // log|D| from the 16 frozen pivots, one per lane and in parallel (a serial log per elimination step costs
     // ~3 us per call on the one wave every other wave is waiting for): pivot r sits in register r >> 2 of lane
     // (r & 3, r).  Lanes 0..15 end up with the block's sum; the caller reads lane 0's.
@@ -475,15 +516,31 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j) {
         }
     __syncthreads();
 
-    // --- blocked Cholesky D = U'U; diagonal sub-blocks end up holding W_kk = U_kk^-1 -------------
+    // --- blocked Cholesky D = U'U and X = U^-1, software-pipelined over the four waves ------------------------------
+    // The serial part is the eight 16x16 eliminations (factor16, one wave, ~5.8 K cycles each).  Wave 0 runs that
+    // chain: in step kb it updates only the NEXT diagonal sub-block with row kb and factors it, while waves 1-3 do the
+    // rest of step kb's trailing update (C) and the column kb of the inverse — so neither waits for the other:
+    //   top of step kb (all waves)  (B) U[kb,cb] = W_kk' D[kb,cb], cb > kb                       | barrier
+    //   wave 0                      D[kb+1,kb+1] -= U[kb,kb+1]'U[kb,kb+1];  factor16 -> W_{kb+1}
+    //   waves 1-3                   store column kb-1 of X (computed last step, held in registers);
+    //                               (C) D[rb,cb] -= U[kb,rb]'U[kb,cb] for the other (rb, cb);
+    //                               X[rb,kb] = -(sum_{rb<=k<kb} X[rb,k] U[k,kb]) W_kk  -> registers           | barrier
+    // A wave owns whole ROWS of X (rows {0,6}, {1,4}, {2,3,5}: balanced), so the X[rb,k] it reads are its own stores,
+    // and a column of X is written one step after it was computed, when nobody reads the U blocks it replaces any more.
+    // Same MFMA chain per element as the unpipelined order: identical results.
     double logsum = 0.0;
     int bad = 0;
     const int lr = q.lr, lk = q.lk;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // rows of X owned by this wave (-1: none); wave 0 owns none
+    const int xrow[3] = {wave_u == 1 ? 0 : wave_u == 2 ? 1 : wave_u == 3 ? 2 : -1,
+                         wave_u == 1 ? 6 : wave_u == 2 ? 4 : wave_u == 3 ? 3 : -1, wave_u == 3 ? 5 : -1};
+    f64x4 pend[3];  // column kb of X for the owned rows, stored at the start of the next step
+    if (wave_u == 0) factor16(S + blk_off(0, 0), lane, 0, logsum, bad);
+    __syncthreads();
     for (int kb = 0; kb < NSB; ++kb) {
-        double *dblk = S + blk_off(kb, kb);
-        if (wave == 0) factor16(dblk, lane, kb * SB, logsum, bad);
-        __syncthreads();
-        for (int cb = kb + 1 + wave; cb < NSB; cb += 4) {  // (B) U[kb,cb] = W_kk' D[kb,cb]
+        double *dblk = S + blk_off(kb, kb);  // W_kk
+        for (int cb = kb + 1 + wave_u; cb < NSB; cb += 4) {  // (B)
             double *blk = S + blk_off(kb, cb);
             f64x4 u = {0.0, 0.0, 0.0, 0.0};
             mfma_tn(u, dblk, SB, blk, SB, lr, lk);
@@ -491,47 +548,71 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j) {
             for (int v = 0; v < 4; ++v) blk[(lk + 4 * v) * SB + lr] = u[v];
         }
         __syncthreads();
-        int pair = 0;
-        for (int rb = kb + 1; rb < NSB; ++rb)  // (C) D[rb,cb] -= U[kb,rb]' U[kb,cb]
-            for (int cb = rb; cb < NSB; ++cb, ++pair) {
-                if ((pair & 3) != wave) continue;
+        if (wave_u == 0) {
+            if (kb + 1 < NSB) {
+                const double *urow = S + blk_off(kb, kb + 1);
+                double *dst = S + blk_off(kb + 1, kb + 1);
                 f64x4 u = {0.0, 0.0, 0.0, 0.0};
-                mfma_tn(u, S + blk_off(kb, rb), SB, S + blk_off(kb, cb), SB, lr, lk);
-                double *dst = S + blk_off(rb, cb);
+                mfma_tn(u, urow, SB, urow, SB, lr, lk);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) dst[(lk + 4 * v) * SB + lr] -= u[v];
-            }
-        __syncthreads();
-    }
-
-    // --- X = U^-1 in place (upper block triangle of S) -------------------------------------------
-    for (int jb = 1; jb < NSB; ++jb) {
-        f64x4 t[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int rb = wave + 4 * s;
-            if (rb < jb)
-                for (int k = rb; k < jb; ++k) mfma_nn(t[s], S + blk_off(rb, k), SB, S + blk_off(k, jb), SB, lr, lk);
-        }
-        __syncthreads();  // every product that reads U[:, jb] is done before the column is overwritten
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int rb = wave + 4 * s;
-            if (rb < jb) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) scratch[(lk + 4 * v) * TS + lr] = t[s][v];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                f64x4 x = {0.0, 0.0, 0.0, 0.0};
-                mfma_nn(x, scratch, TS, S + blk_off(jb, jb), SB, lr, lk);
-                double *dst = S + blk_off(rb, jb);
+                factor16(dst, lane, (kb + 1) * SB, logsum, bad);
+            }
+        } else {
+            if (kb >= 2) {  // column kb-1 of X, computed in the previous step
 #pragma unroll
-                for (int v = 0; v < 4; ++v) dst[(lk + 4 * v) * SB + lr] = -x[v];
+                for (int i = 0; i < 3; ++i)
+                    if (xrow[i] >= 0 && xrow[i] < kb - 1) {
+                        double *dst = S + blk_off(xrow[i], kb - 1);
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) dst[(lk + 4 * v) * SB + lr] = pend[i][v];
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+            }
+            int pair = 0;
+            for (int rb = kb + 1; rb < NSB; ++rb)  // (C), all but the next diagonal sub-block
+                for (int cb = rb; cb < NSB; ++cb) {
+                    if (rb == kb + 1 && cb == kb + 1) continue;
+                    if (pair++ % 3 + 1 != wave_u) continue;
+                    f64x4 u = {0.0, 0.0, 0.0, 0.0};
+                    mfma_tn(u, S + blk_off(kb, rb), SB, S + blk_off(kb, cb), SB, lr, lk);
+                    double *dst = S + blk_off(rb, cb);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) dst[(lk + 4 * v) * SB + lr] -= u[v];
+                }
+            if (kb >= 1) {  // column kb of X for the owned rows above the diagonal
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    if (xrow[i] >= 0 && xrow[i] < kb) {
+                        const int rb = xrow[i];
+                        f64x4 t = {0.0, 0.0, 0.0, 0.0};
+                        for (int k = rb; k < kb; ++k) mfma_nn(t, S + blk_off(rb, k), SB, S + blk_off(k, kb), SB, lr, lk);
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) scratch[(lk + 4 * v) * TS + lr] = t[v];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        f64x4 x = {0.0, 0.0, 0.0, 0.0};
+                        mfma_nn(x, scratch, TS, dblk, SB, lr, lk);
+                        pend[i] = -x;
+                        __builtin_amdgcn_wave_barrier();
+                    }
             }
         }
         __syncthreads();
     }
+    if (wave_u != 0) {  // last column of X
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (xrow[i] >= 0 && xrow[i] < NSB - 1) {
+                double *dst = S + blk_off(xrow[i], NSB - 1);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) dst[(lk + 4 * v) * SB + lr] = pend[i][v];
+            }
+    }
+    __syncthreads();
 
     // --- W_j out (explicit zeros below the diagonal: solve_kernel multiplies the full tile) -----
     double *Wb = p.W + (size_t)b * NB * NB;
