@@ -100,39 +100,6 @@ __device__ __forceinline__ void zero_acc(f64x4 (&acc)[4][4]) {
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f64x4){0.0, 0.0, 0.0, 0.0};
 }
 
-struct StageRegs {
-    f64x2 a0, a1, a2, a3, b0, b1, b2, b3;
-};
-
-// global -> registers: stage kt of both panels; thread (lrow, lcol) moves 4 x 16 B per operand
-__device__ __forceinline__ void stage_load(StageRegs &r, const double *__restrict__ A, long lda,
-                                           const double *__restrict__ B, long ldb, int kt, int lrow, int lcol) {
-    const double *a = A + ((long)kt * BK + lrow) * lda + lcol;
-    const double *b = B + ((long)kt * BK + lrow) * ldb + lcol;
-    r.a0 = *reinterpret_cast<const f64x2 *>(a);
-    r.a1 = *reinterpret_cast<const f64x2 *>(a + 4 * lda);
-    r.a2 = *reinterpret_cast<const f64x2 *>(a + 8 * lda);
-    r.a3 = *reinterpret_cast<const f64x2 *>(a + 12 * lda);
-    r.b0 = *reinterpret_cast<const f64x2 *>(b);
-    r.b1 = *reinterpret_cast<const f64x2 *>(b + 4 * ldb);
-    r.b2 = *reinterpret_cast<const f64x2 *>(b + 8 * ldb);
-    r.b3 = *reinterpret_cast<const f64x2 *>(b + 12 * ldb);
-}
-
-// registers -> LDS stage image As[k][LDS_LD] | Bs[k][LDS_LD]
-__device__ __forceinline__ void stage_store(const StageRegs &r, double *st, int lrow, int lcol) {
-    double *as = st + lrow * LDS_LD + lcol;
-    double *bs = as + BK * LDS_LD;
-    *reinterpret_cast<f64x2 *>(as) = r.a0;
-    *reinterpret_cast<f64x2 *>(as + 4 * LDS_LD) = r.a1;
-    *reinterpret_cast<f64x2 *>(as + 8 * LDS_LD) = r.a2;
-    *reinterpret_cast<f64x2 *>(as + 12 * LDS_LD) = r.a3;
-    *reinterpret_cast<f64x2 *>(bs) = r.b0;
-    *reinterpret_cast<f64x2 *>(bs + 4 * LDS_LD) = r.b1;
-    *reinterpret_cast<f64x2 *>(bs + 8 * LDS_LD) = r.b2;
-    *reinterpret_cast<f64x2 *>(bs + 12 * LDS_LD) = r.b3;
-}
-
 // one k-tile (16 deep) of MFMAs from LDS stage `st`
 __device__ __forceinline__ void mma_stage(f64x4 (&acc)[4][4], const double *st, const Lane &q) {
     const double *As = st;
@@ -178,8 +145,9 @@ __device__ __forceinline__ void stage_dma(const double *__restrict__ A, long lda
     }
 }
 
-// DMA-staged variant of gemm_kmajor (same contract).  Tile t+1 is in flight into the other stage
-// while tile t is multiplied; the wait + barrier at the end of the iteration publishes it.
+// acc[r][c] += sum_{k<K} A[k][r] * B[k][c] for a 128x128 tile; A, B k-major panels (row stride lda/ldb, 128 contiguous
+// doubles per row, 16-byte aligned), K % 16 == 0.  All 256 threads; ends with a barrier.  Tile t+1 is in flight into
+// the other LDS stage while tile t is multiplied; the wait + barrier at the end of the iteration publishes it.
 __device__ __forceinline__ void gemm_kmajor_dma(f64x4 (&acc)[4][4], const double *__restrict__ A, long lda,
                                                 const double *__restrict__ B, long ldb, int K, double *lds, int tid,
                                                 const Lane &q) {
@@ -193,31 +161,6 @@ __device__ __forceinline__ void gemm_kmajor_dma(f64x4 (&acc)[4][4], const double
         if (kt + 1 < nk) stage_dma(A, lda, B, ldb, kt + 1, lds + ((kt + 1) & 1) * STAGE, wave, lane);
         mma_stage(acc, lds + (kt & 1) * STAGE, q);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-}
-
-// acc[r][c] += sum_{k<K} A[k][r] * B[k][c]   for a 128x128 tile; A, B k-major panels (row stride lda/ldb,
-// 128 contiguous doubles per row, 16-byte aligned).  K % 16 == 0.  All 256 threads; ends with a barrier.
-// Register-staged double buffer: tile t+1 travels global -> VGPR while tile t is multiplied, then
-// VGPR -> LDS (ds_write_b128) before the barrier.  Used by the short K = 128 products (diag kernel); the
-// long panel products use the LDS-DMA variant above, which avoids the ds_write bursts.
-__device__ __forceinline__ void gemm_kmajor(f64x4 (&acc)[4][4], const double *__restrict__ A, long lda,
-                                            const double *__restrict__ B, long ldb, int K, double *lds, int tid,
-                                            const Lane &q) {
-    const int nk = K / BK;
-    if (nk == 0) return;
-    // thread -> (row k, column pair) of a stage: 4 passes of 256 threads x 16 B cover 16 rows x 1 KiB
-    const int lrow = tid >> 6, lcol = (tid & 63) * 2;
-    StageRegs regs;
-    stage_load(regs, A, lda, B, ldb, 0, lrow, lcol);
-    stage_store(regs, lds, lrow, lcol);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) stage_load(regs, A, lda, B, ldb, kt + 1, lrow, lcol);
-        mma_stage(acc, lds + (kt & 1) * STAGE, q);
-        if (more) stage_store(regs, lds + ((kt + 1) & 1) * STAGE, lrow, lcol);
         __syncthreads();
     }
 }
@@ -476,6 +419,80 @@ __device__ __forceinline__ void factor16(double *blk, int lane, int base_index, 
     }
 }
 
+// Rank-128 update of the diagonal tile, upper block triangle only: D = P - U[j-1,j]' U[j-1,j] for the 36 sub-blocks
+// (rb <= cb), nine per wave (wave W takes block row W from the diagonal to the right edge plus the short rows at the
+// bottom: 8+1, 7+2, 6+3, 5+4), written straight into the packed factor image S.  Both MFMA operands come from the SAME
+// k-major panel, so one LDS-DMA stage of 16 x 128 doubles serves A and B fragments; the P values are requested before
+// the product loop.  A full 128 x 128 product with 64 x 64 wave tiles would leave one wave computing only discarded
+// sub-blocks (41 K cycles against 22 K here).  Per element the MFMA sequence is k-ascending, as everywhere.
+template <int W>
+struct UpperBlocks;
+template <>
+struct UpperBlocks<0> {
+    static constexpr int rb[9] = {0, 0, 0, 0, 0, 0, 0, 0, 7}, cb[9] = {0, 1, 2, 3, 4, 5, 6, 7, 7};
+};
+template <>
+struct UpperBlocks<1> {
+    static constexpr int rb[9] = {1, 1, 1, 1, 1, 1, 1, 6, 6}, cb[9] = {1, 2, 3, 4, 5, 6, 7, 6, 7};
+};
+template <>
+struct UpperBlocks<2> {
+    static constexpr int rb[9] = {2, 2, 2, 2, 2, 2, 5, 5, 5}, cb[9] = {2, 3, 4, 5, 6, 7, 5, 6, 7};
+};
+template <>
+struct UpperBlocks<3> {
+    static constexpr int rb[9] = {3, 3, 3, 3, 3, 4, 4, 4, 4}, cb[9] = {3, 4, 5, 6, 7, 4, 5, 6, 7};
+};
+
+constexpr int UPD_STAGE = BK * LDS_LD;  // one operand: 16 rows x (128 + 16) doubles
+
+template <int W>
+__device__ __forceinline__ void diag_update(const double *__restrict__ tile, long ld, const double *__restrict__ panel,
+                                            bool has_panel, double *lds, double *S, int lane, int lr, int lk) {
+    using T = UpperBlocks<W>;
+    double pre[9][4];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) pre[i][v] = tile[(size_t)(T::rb[i] * 16 + lk + 4 * v) * ld + T::cb[i] * 16 + lr];
+    f64x4 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    if (has_panel) {  // workgroup-uniform: every wave takes the same barriers
+        auto stage = [&](int kt, double *st) {  // wave W moves rows W, W+4, W+8, W+12 of the k-tile
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp)
+                dma_row(panel + (size_t)(kt * BK + W + 4 * pp) * ld + lane * 2, st + (W + 4 * pp) * LDS_LD);
+        };
+        stage(0, lds);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int kt = 0; kt < NB / BK; ++kt) {
+            if (kt + 1 < NB / BK) stage(kt + 1, lds + ((kt + 1) & 1) * UPD_STAGE);
+            const double *st = lds + (kt & 1) * UPD_STAGE;
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                double fr[8];
+#pragma unroll
+                for (int blk = 0; blk < 8; ++blk)
+                    if (blk >= W) fr[blk] = st[(kk * 4 + lk) * LDS_LD + blk * 16 + lr];
+#pragma unroll
+                for (int i = 0; i < 9; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[T::rb[i]], fr[T::cb[i]], acc[i], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        double *blk = S + blk_off(T::rb[i], T::cb[i]);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) blk[(lk + 4 * v) * SB + lr] = pre[i][v] - acc[i][v];
+    }
+}
+
 __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, b = blockIdx.x;
@@ -490,30 +507,24 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j) {
     const double acc_logdet = tid == 0 ? p.accum[(size_t)b * 2 + 1] : 0.0;
     const int info_in = tid == 0 ? p.info[b] : 0;
 
-    f64x4 acc[4][4];
-    zero_acc(acc);
-    if (j > 0) {
-        const double *prev = Ab + (size_t)(j - 1) * NB * p.ld + (size_t)j * NB;  // U[j-1, j]
-        gemm_kmajor(acc, prev, p.ld, prev, p.ld, NB, lds, tid, q);
-    }
     double *S = lds;                                          // packed upper block triangle, NBLK x [16][16]
     double *scratch = lds + NBLK * SB * SB + wave * SB * TS;  // per-wave [16][TS]
     double *vec = lds + NBLK * SB * SB + 4 * SB * TS;         // [2][128] y | upper-half partial sums
     double *red = vec + 2 * NB;                               // [8]
-    // D = P - U[j-1,j]'U[j-1,j]: only sub-blocks on or above the block diagonal are kept
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int rbk = (q.wr * 64 + mt * 16) >> 4, cbk = (q.wc * 64 + nt * 16) >> 4;  // wave-uniform
-            if (rbk <= cbk) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int r = acc_row(q, mt, v), c = acc_col(q, nt);
-                    s_at(S, r, c) = tile[(size_t)r * p.ld + c] - acc[mt][nt][v];
-                }
-            }
-        }
+    {
+        // D = P - U[j-1,j]'U[j-1,j] on the upper block triangle (the product stages alias S: the update's last barrier
+        // precedes the writes of S)
+        const double *prev = Ab + (size_t)(j > 0 ? j - 1 : 0) * NB * p.ld + (size_t)j * NB;  // U[j-1, j]
+        const int wsel = __builtin_amdgcn_readfirstlane(wave);
+        if (wsel == 0)
+            diag_update<0>(tile, p.ld, prev, j > 0, lds, S, lane, q.lr, q.lk);
+        else if (wsel == 1)
+            diag_update<1>(tile, p.ld, prev, j > 0, lds, S, lane, q.lr, q.lk);
+        else if (wsel == 2)
+            diag_update<2>(tile, p.ld, prev, j > 0, lds, S, lane, q.lr, q.lk);
+        else
+            diag_update<3>(tile, p.ld, prev, j > 0, lds, S, lane, q.lr, q.lk);
+    }
     __syncthreads();
 
     // --- blocked Cholesky D = U'U and X = U^-1, software-pipelined over the four waves ------------------------------
@@ -614,27 +625,35 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j) {
     }
     __syncthreads();
 
-    // --- W_j out (explicit zeros below the diagonal: solve_kernel multiplies the full tile) -----
+    // --- W_j out, sub-block by sub-block (explicit zeros below the block diagonal: solve_kernel multiplies the full
+    // tile; the diagonal sub-blocks are upper triangular with exact zeros already) --------------------------------
     double *Wb = p.W + (size_t)b * NB * NB;
-    for (int e = tid; e < NB * NB; e += THREADS) {
-        const int r = e >> 7, cc = e & (NB - 1);
-        Wb[e] = (r <= cc) ? s_at(S, r, cc) : 0.0;
+    {
+        const int r = tid >> 4, c = tid & 15;  // one element of every 16 x 16 sub-block per thread
+#pragma unroll
+        for (int rbk = 0; rbk < NSB; ++rbk)
+#pragma unroll
+            for (int cbk = 0; cbk < NSB; ++cbk)
+                Wb[(size_t)(rbk * SB + r) * NB + cbk * SB + c] = rbk <= cbk ? S[blk_off(rbk, cbk) + tid] : 0.0;
     }
 
     // --- z_j = W_j' y_j ; quad += |z_j|^2 ; logdet += 2 sum log u_kk ----------------------------
-    // thread (c, half) sums rows half*64 .. half*64+63 of column c (rows <= c only: W_j is upper triangular);
-    // fixed trip count, so the LDS reads pipeline.  y_j and the accumulators were loaded at kernel entry.
+    // thread (c, half) sums the sub-block rows 4*half .. 4*half+3 of column c (only sub-blocks on or above the block
+    // diagonal exist: W_j is upper triangular).  y_j and the accumulators were loaded at kernel entry.
     double *yb = p.yz + (size_t)b * p.nrb * NB + (size_t)j * NB;
     if (tid < NB) vec[tid] = y_in;
     __syncthreads();
     {
-        const int c = tid & (NB - 1), half = tid >> 7;
+        const int c = tid & (NB - 1), half = tid >> 7, cbk = c >> 4, cc = c & 15;
         double part = 0.0;
-#pragma unroll 8
-        for (int i = 0; i < NB / 2; ++i) {
-            const int r = half * (NB / 2) + i;
-            const double w = s_at(S, min(r, c), c);
-            part = fma(r <= c ? w : 0.0, vec[r], part);
+#pragma unroll
+        for (int i = 0; i < NSB / 2; ++i) {
+            const int rbk = half * (NSB / 2) + i;
+            if (rbk <= cbk) {
+                const double *col = S + blk_off(rbk, cbk) + cc;
+#pragma unroll
+                for (int rr = 0; rr < SB; ++rr) part = fma(col[rr * SB], vec[rbk * SB + rr], part);
+            }
         }
         if (half) vec[NB + c] = part;  // vec has 2 * NB doubles
         __syncthreads();
