@@ -325,7 +325,8 @@ __device__ __forceinline__ double row_bcast_f64(double v) {
 //     row broadcasts and pushed through the block's unit-lower factor, then applied as one rank-4 update.
 // The per-element operation order is that of four single-pivot steps.
 template <int Q>
-__device__ __forceinline__ void block4(double (&e)[4], double (&f)[4], int c, int g, int base_index, int &bad) {
+__device__ __forceinline__ void block4(double (&e)[4], double (&f)[4], double (&piv)[4][4], int c, int g, int base_index,
+                                       int &bad) {
     constexpr int K0 = 4 * Q;
     double A0 = __shfl(e[Q], 0 * 16 + c), A1 = __shfl(e[Q], 1 * 16 + c), A2 = __shfl(e[Q], 2 * 16 + c),
            A3 = __shfl(e[Q], 3 * 16 + c);  // D[K0 + j][c]
@@ -353,6 +354,10 @@ __device__ __forceinline__ void block4(double (&e)[4], double (&f)[4], int c, in
     const double l32 = t23 * rd2;
     const double d3 = fma(-l32, t23, fma(-l31, t13, fma(-l30, P03, P33)));
     const double rd3 = pivot(d3, 3);
+    piv[Q][0] = P00;  // the frozen pivots, wave-uniform (factor16's tail needs no cross-lane traffic for them)
+    piv[Q][1] = d1;
+    piv[Q][2] = d2;
+    piv[Q][3] = d3;
     // the block's own rows after its four steps, at this lane's column
     A1 = fma(-l10, A0, A1);
     A2 = fma(-l21, A1, fma(-l20, A0, A2));
@@ -380,7 +385,7 @@ __device__ __forceinline__ void block4(double (&e)[4], double (&f)[4], int c, in
     // lane group j owns row K0 + j of the block
     e[Q] = g == 0 ? A0 : g == 1 ? A1 : g == 2 ? A2 : A3;
     f[Q] = g == 0 ? S0 : g == 1 ? S1 : g == 2 ? S2 : S3;
-    if constexpr (Q + 1 < 4) block4<Q + 1>(e, f, c, g, base_index, bad);
+    if constexpr (Q + 1 < 4) block4<Q + 1>(e, f, piv, c, g, base_index, bad);
 }
 
 __device__ __forceinline__ void factor16(double *blk, int lane, int base_index, double &logsum, int &bad) {
@@ -391,31 +396,36 @@ __device__ __forceinline__ void factor16(double *blk, int lane, int base_index, 
         e[v] = blk[(g + 4 * v) * SB + c];
         f[v] = (g + 4 * v == c) ? 1.0 : 0.0;
     }
-    block4<0>(e, f, c, g, base_index, bad);
-    // log|D| from the 16 frozen pivots, one per lane and in parallel (a serial log per elimination step costs
-    // ~3 us per call on the one wave every other wave is waiting for): pivot r sits in register r >> 2 of lane
-    // (r & 3, r).  Lanes 0..15 end up with the block's sum; the caller reads lane 0's.
+    double piv[4][4];  // piv[q][i] = pivot of row 4q + i, identical in every lane
+    block4<0>(e, f, piv, c, g, base_index, bad);
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (!(piv[qq][i] > 0.0)) piv[qq][i] = 1.0;  // flagged above; keep the rest finite
+    // log|D| = sum of the 16 log pivots: lane l takes the product of block (l & 3)'s four pivots — one log per lane —
+    // and the four values meet by two quad-permute DPP adds (a log per elimination step, or a 16-lane ds_bpermute
+    // reduction, costs more than the rest of this tail)
     {
-        const int r = lane & 15;
-        double piv = 1.0;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const double dv = __shfl(e[v], (r & 3) * 16 + r);
-            if ((r >> 2) == v) piv = dv;
-        }
-        if (!(piv > 0.0)) piv = 1.0;
-        double lg = log(piv);
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) lg += __shfl_xor(lg, off);
+        const int sel = lane & 3;
+        const double p0 = (piv[0][0] * piv[0][1]) * (piv[0][2] * piv[0][3]), p1 = (piv[1][0] * piv[1][1]) * (piv[1][2] * piv[1][3]),
+                     p2 = (piv[2][0] * piv[2][1]) * (piv[2][2] * piv[2][3]), p3 = (piv[3][0] * piv[3][1]) * (piv[3][2] * piv[3][3]);
+        double lg = log(sel == 0 ? p0 : sel == 1 ? p1 : sel == 2 ? p2 : p3);
+        lg += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(lg), 0xB1, 0xF, 0xF, false),   // quad_perm [1,0,3,2]
+                               __builtin_amdgcn_update_dpp(0, __double2loint(lg), 0xB1, 0xF, 0xF, false));
+        lg += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(lg), 0x4E, 0xF, 0xF, false),   // quad_perm [2,3,0,1]
+                               __builtin_amdgcn_update_dpp(0, __double2loint(lg), 0x4E, 0xF, 0xF, false));
         logsum += 0.5 * lg;
     }
-    // row r of the right half is (L~^-1)[r][:]; U^-T = diag(1/sqrt d) L~^-1, so W[c][r] = f * rsqrt(d_r)
+    // row r of the right half is (L~^-1)[r][:]; U^-T = diag(1/sqrt d) L~^-1, so W[c][r] = f * rsqrt(d_r), r = g + 4v:
+    // pivot g of block v.  1/sqrt by v_rsq_f64 + two Newton steps (full double accuracy; IEEE sqrt + divide is ~4x longer)
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        const int r = g + 4 * v;
-        double dr = __shfl(e[v], g * 16 + r);  // frozen pivot of row r: lane (g, c == r), same register
-        if (!(dr > 0.0)) dr = 1.0;
-        blk[c * SB + r] = f[v] / sqrt(dr);
+        const double dr = g == 0 ? piv[v][0] : g == 1 ? piv[v][1] : g == 2 ? piv[v][2] : piv[v][3];
+        double rs = __builtin_amdgcn_rsq(dr);
+        rs = rs * fma(-0.5 * dr * rs, rs, 1.5);
+        rs = rs * fma(-0.5 * dr * rs, rs, 1.5);
+        blk[c * SB + (g + 4 * v)] = f[v] * rs;
     }
 }
 

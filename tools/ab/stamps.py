@@ -11,10 +11,10 @@ torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 32)()
 assert _lib.lib().bark_debug_stamps(buf) == 0
 t = list(buf)
-names = {0: "start", 1: "rank-128 update done", 2: "assembled D", 7: "factor16(0) done", 3: "pipelined factor+inverse loop done", 4: "last X column stored",
+names = {0: "start", 2: "rank-128 update + assembly done", 7: "factor16(0) done", 3: "pipelined factor+inverse loop done", 4: "last X column stored",
          5: "W written", 6: "z / sums done"}
 prev = t[0]
-for i in (1, 2, 7, 3, 4, 5, 6):
+for i in (2, 7, 3, 4, 5, 6):
     print(f"{names[i]:36s} {t[i]-t[0]:8d} cyc  (+{t[i]-prev})")
     prev = t[i]
 print("step kb=3: (B)+barrier", t[11] - t[10], "| wave0 C+factor16", t[12] - t[11], "| wave1 work", t[15] - t[14], "| closing barrier (wave 0)", t[13] - t[12])
