@@ -1072,6 +1072,13 @@ __global__ __launch_bounds__(THREADS) void quadform_kernel(const double *__restr
 
 constexpr int SPLITK_SLOTS = 512;  // workgroup slots split-K aims to fill (2 per CU)
 constexpr int SPLITK_MAX = 16;
+#ifndef BARK_SPLITK_LAYOUT_MAX_TILES
+#define BARK_SPLITK_LAYOUT_MAX_TILES 1100
+#endif
+// Chunks with fewer tiles per block row than this reserve the slab scratch and materialise A, so that their
+// under-filled steps can split K (build-time tuning constant; measured at N = 4096: B = 8 9.97 -> 5.62 ms, B = 16
+// 11.6 -> 9.4 ms, B = 32 16.9 -> 16.3 ms, no gain from B = 64 on)
+constexpr int SPLITK_LAYOUT_MAX_TILES = BARK_SPLITK_LAYOUT_MAX_TILES;
 
 struct Layout {
     int64_t npad, cpad, ncols, ld, W;
@@ -1102,7 +1109,7 @@ Layout make_layout(int64_t N, int64_t C, int64_t m, int64_t Bc) {
     L.off_leafc = o;
     o = align256(o + (size_t)Bc * L.W * L.cpad * sizeof(uint32_t));
     L.off_slab = o;
-    L.splitk = Bc * (L.ncols / NB) < SPLITK_SLOTS / 2 && L.npad / NB >= 4;
+    L.splitk = Bc * (L.ncols / NB) < SPLITK_LAYOUT_MAX_TILES && L.npad / NB >= 4;
     if (L.splitk) o = align256(o + (size_t)(SPLITK_SLOTS + SPLITK_MAX * Bc) * NB * NB * sizeof(double));
     L.total = o;
     return L;

@@ -216,6 +216,32 @@ class Workload:
         spans = sorted(e[i].elapsed_time(e[i + 1]) for i in range(reps))
         return sum(spans) / reps, spans[len(spans) // 2]
 
+    def graph_ms(self, reps):
+        """Device time of one call replayed from a captured hipGraph (the `*_hip` entry points only enqueue work, so a
+        latency-bound caller can capture the launch sequence once and replay it): median over `reps` replays."""
+        import torch
+
+        from bark_amd import _lib
+
+        self.run()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        keep = self.stream
+        with torch.cuda.graph(g):
+            self.stream = _lib.stream_ptr()  # the capture stream
+            self.run()
+        self.stream = keep
+        g.replay()
+        torch.cuda.synchronize()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        e[0].record()
+        for i in range(reps):
+            g.replay()
+            e[i + 1].record()
+        torch.cuda.synchronize()
+        spans = sorted(e[i].elapsed_time(e[i + 1]) for i in range(reps))
+        return spans[len(spans) // 2]
+
     def check(self):
         import numpy as np
 
@@ -476,18 +502,23 @@ def extras(args, wl, result, mll_host):
     if not args.no_configs and N == 4096:
         cfgs = []
 
-        def entry(name, w, reps_):
+        def entry(name, w, reps_, graph=False):
             avg, med = w.device_ms(reps_)
             w.check()
             flops = w.B * (w.N**3 / 3.0 + (float(w.N) * w.N * w.C if w.C else 0.0))
             tf = flops / (med * 1e-3) / 1e12
-            cfgs.append({"config": name, "N": w.N, "B": w.B, "C": w.C, "device_ms": med, "device_ms_mean": avg,
-                         "evals_per_s": w.B / (med * 1e-3), "tflops": tf, "frac_of_f64_mfma_peak": tf / F64_MFMA_PEAK_TFLOPS})
+            row = {"config": name, "N": w.N, "B": w.B, "C": w.C, "device_ms": med, "device_ms_mean": avg,
+                   "evals_per_s": w.B / (med * 1e-3), "tflops": tf, "frac_of_f64_mfma_peak": tf / F64_MFMA_PEAK_TFLOPS}
+            if graph:  # launch-bound sizes: the same call replayed from a hipGraph
+                row["graph_replay_ms"] = w.graph_ms(reps_)
+                w.check()
+            cfgs.append(row)
 
-        entry("c2: N=1024 d=8 m=50, single forest", Workload(1024, 8, m, 1, 1024, 0), 20)
+        entry("c2: N=1024 d=8 m=50, single forest", Workload(1024, 8, m, 1, 1024, 0), 20, graph=True)
         entry("c4 per-GPU share: N=4096, 64 forests", Workload(4096, d, m, 64, N, 0), 5)
         entry("small batch: N=4096, 16 forests", Workload(4096, d, m, 16, N, 0), 5)
-        entry("lone matrix: N=4096, 1 forest", Workload(4096, d, m, 1, N, 0), 10)
+        entry("small batch: N=4096, 8 forests", Workload(4096, d, m, 8, N, 0), 5)
+        entry("lone matrix: N=4096, 1 forest", Workload(4096, d, m, 1, N, 0), 10, graph=True)
         torch.cuda.empty_cache()
         w5 = Workload(16384, 12, m, 1, 16384, 0, problem="mixed", include_scale=True)
         entry("c5 MLL: N=16384 mixed cat+int+cont, single forest", w5, 3)

@@ -149,7 +149,8 @@ def test_c4_512_samples_sharded_equal_unsharded():
     total, N = 512, 4096
     X, y, bounds, ft = synthetic.unit_cube_problem(N, 8, seed=N)
     noise = np.random.default_rng(7).uniform(0.05, 0.15, total)
-    pick = [0, 1, 127, 128, 255, 256, 383, 511]  # shard edges (8 forests: enough resident matrices for the non-split-K path)
+    pick = sorted(set([0, 1, 127, 128, 255, 256, 383, 511] + list(range(5, 512, 16))))  # shard edges + a spread: 40 forests,
+    # enough resident matrices for the non-split-K schedule the 128-forest shards ran
     F = np.stack([synthetic.sample_prior_forests(1, 50, bounds, ft, seed=N + b)[0] for b in pick])
     one = fit.batched_mll(F, noise[pick], None, X, y, ft, include_scale=False, include_2pi=True)
     assert np.array_equal(results[0][pick], one)  # a forest's bits do not depend on the shard or chunk it sits in

@@ -590,7 +590,7 @@ def test_single_large_matrix_split_k_path(B):
 
 def test_many_small_matrices_and_chunk_invariance(B):
     """B = 288 forests at N = 700 (6 block rows): a filled chip of small matrices against the oracle's LU route, and
-    the same forests factorised 64 at a time: without split-K a forest's result does not depend on the chunk it
+    the same forests factorised 192 at a time: without split-K a forest's result does not depend on the chunk it
     sits in (identical bits).  Also with candidates (materialised A, candidate columns carry no right-hand side)."""
     nb, N = 288, 700
     X, y, bounds, ft = B.syn.mixed_problem(N, seed=31)
@@ -601,7 +601,7 @@ def test_many_small_matrices_and_chunk_invariance(B):
     want = B.orc.batched_mll(F[sub], noise[sub], scale[sub], X, y, ft, include_scale=True, include_2pi=True)
     fused = B.fit.batched_mll(F, noise, scale, X, y, ft, include_scale=True, include_2pi=True)
     assert np.allclose(fused[sub], want, rtol=MLL_RTOL, atol=MLL_ATOL), np.abs(fused[sub] - want).max()
-    small = B.fit.batched_mll(F, noise, scale, X, y, ft, include_scale=True, include_2pi=True, chunk=64)
+    small = B.fit.batched_mll(F, noise, scale, X, y, ft, include_scale=True, include_2pi=True, chunk=192)
     assert np.array_equal(fused, small)
     # ragged last chunk, other convention
     part = B.fit.batched_mll(F, noise, None, X, y, ft, include_scale=False, include_2pi=True, chunk=200)
@@ -614,7 +614,7 @@ def test_many_small_matrices_and_chunk_invariance(B):
     assert np.allclose(mu[:24], mu0, rtol=1e-9, atol=1e-9) and np.allclose(var[:24], var0, rtol=1e-9, atol=1e-9)
     from bark_amd.fitting.mll import _run
     import bark_amd._lib as L
-    _, mu8, var8 = _run(F, noise, scale, X, y, ft, L.MLL_INCLUDE_SCALE, cand=cand, chunk=64)
+    _, mu8, var8 = _run(F, noise, scale, X, y, ft, L.MLL_INCLUDE_SCALE, cand=cand, chunk=200)
     assert np.array_equal(mu8.cpu().numpy(), mu) and np.array_equal(var8.cpu().numpy(), var)
 
 
