@@ -810,12 +810,14 @@ __global__ __launch_bounds__(THREADS, 2) void row_kernel(Mats p, int j, int n_ri
 
 // ---------------------------------------------------------------------------------------------
 // Split-K variant of the panel update for under-filled steps (few matrices x few tiles, e.g. one
-// N = 16384 matrix): the K = 128 j range of every tile is cut into S contiguous slabs, each accumulated by
-// its own workgroup into a scratch slab; panel_reduce_kernel then forms T = A - sum_s slab_s in a fixed
-// order (deterministic, unlike atomics).  Tile index t' = tile * S + s.
+// N = 16384 matrix): the block rows [kb_lo, kb_hi) of every tile's K range are cut into S contiguous slabs, each
+// accumulated by its own workgroup into slot s_off + s of the tile's S_tot scratch slabs; panel_reduce_kernel then
+// forms T = A - sum over the S_tot slabs in a fixed order (deterministic, unlike atomics).  Tile index t' = tile * S + s.
+// One launch over [0, j) is the plain split; the look-ahead schedule (Sweep::step) makes two: the bulk [0, j-1) one
+// step early and the last block row [j-1, j) on the critical path.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(Mats p, int j, int n_right, int n_tiles, int S,
-                                                                  double *slabs) {
+__global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(Mats p, int j, int n_right, int n_tiles, int kb_lo, int kb_hi,
+                                                                  int S, int s_off, int S_tot, double *slabs) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
     int b, ts;
@@ -823,12 +825,13 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(Mats p, int j, 
     const Lane q = lane_of(tid);
     const int t = ts / S, s = ts - t * S;
     const int rb = t < n_right ? j : j + 1, cb = t < n_right ? j + 1 + t : j + 1;
-    const int kb0 = (int)(((long)j * s) / S), kb1 = (int)(((long)j * (s + 1)) / S);  // block rows [kb0, kb1)
+    const int nkb = kb_hi - kb_lo;
+    const int kb0 = kb_lo + (int)(((long)nkb * s) / S), kb1 = kb_lo + (int)(((long)nkb * (s + 1)) / S);  // block rows [kb0, kb1)
     const double *Ab = p.A + (size_t)b * p.bstride + (size_t)kb0 * NB * p.ld;
     f64x4 acc[4][4];
     zero_acc(acc);
     gemm_kmajor_dma(acc, Ab + (size_t)rb * NB, p.ld, Ab + (size_t)cb * NB, p.ld, (kb1 - kb0) * NB, lds, tid, q);
-    double *slab = slabs + ((size_t)((size_t)b * n_tiles + t) * S + s) * NB * NB;
+    double *slab = slabs + ((size_t)((size_t)b * n_tiles + t) * S_tot + s_off + s) * NB * NB;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -1072,6 +1075,18 @@ __global__ __launch_bounds__(THREADS) void quadform_kernel(const double *__restr
 
 constexpr int SPLITK_SLOTS = 512;  // workgroup slots split-K aims to fill (2 per CU)
 constexpr int SPLITK_MAX = 16;
+constexpr size_t SLAB_SET_TILES = SPLITK_SLOTS + SPLITK_SLOTS / 2;  // slabs (128 x 128) of one set
+#ifndef BARK_LA_SLOTS
+#define BARK_LA_SLOTS 448
+#endif
+// The look-ahead bulk of a split-K step runs beside the previous step's critical path (diag, rank-128 slab, reduce,
+// solve): it is cut into fewer workgroups than the chip has slots, so that those small kernels find a free slot while
+// the bulk's single round of equal workgroups is resident (resident workgroups are never pre-empted).
+constexpr int LA_SLOTS = BARK_LA_SLOTS;
+#ifndef BARK_LA_MIN_WORK
+#define BARK_LA_MIN_WORK 600
+#endif
+constexpr long LA_MIN_WORK = BARK_LA_MIN_WORK;
 #ifndef BARK_SPLITK_LAYOUT_MAX_TILES
 #define BARK_SPLITK_LAYOUT_MAX_TILES 1100
 #endif
@@ -1110,7 +1125,9 @@ Layout make_layout(int64_t N, int64_t C, int64_t m, int64_t Bc) {
     o = align256(o + (size_t)Bc * L.W * L.cpad * sizeof(uint32_t));
     L.off_slab = o;
     L.splitk = Bc * (L.ncols / NB) < SPLITK_LAYOUT_MAX_TILES && L.npad / NB >= 4;
-    if (L.splitk) o = align256(o + (size_t)(SPLITK_SLOTS + SPLITK_MAX * Bc) * NB * NB * sizeof(double));
+    // two slab sets (look-ahead: the bulk of step j+1 is accumulated while step j is reduced); a split step has fewer
+    // than SPLITK_SLOTS / 2 tiles x matrices, S of at most SPLITK_SLOTS / that, plus one slab for the last block row
+    if (L.splitk) o = align256(o + (size_t)2 * SLAB_SET_TILES * NB * NB * sizeof(double));
     L.total = o;
     return L;
 }
@@ -1164,6 +1181,8 @@ namespace {
 struct Sweep {
     Mats p;
     hipStream_t main = nullptr, panel = nullptr;  // panel == main: no overlap
+    hipStream_t la_stream = nullptr;              // look-ahead launches of the split-K bulk (null: no look-ahead)
+    int nrb_steps = 0;                            // block columns that get a step() (== nrb)
     bark_ctx *res = nullptr;
     int nrb = 0, ncb = 0;
     bool fused = false, splitk = false;
@@ -1222,10 +1241,50 @@ struct Sweep {
         return BARK_OK;
     }
 
+    // split-K factor of step j over nkb block rows: fill ~SPLITK_SLOTS workgroup slots, >= 1 block row per slab
+    int split_factor(int j, int nkb, int slots = SPLITK_SLOTS) const {
+        const int n_tiles = (ncb - j - 1) + ((j + 1 < nrb) ? 1 : 0);
+        if (!splitk || j < 1 || n_tiles <= 0 || n_tiles * p.Bc >= SPLITK_SLOTS / 2 || nkb < 1) return 1;
+        int S = slots / (n_tiles * p.Bc);
+        if (S < 1) S = 1;
+        if (S > nkb) S = nkb;
+        if (S > SPLITK_MAX) S = SPLITK_MAX;
+        return S;
+    }
+    // look-ahead step: split layout, under-filled, and at least one block row besides the last (j >= 2)
+    // ... and a bulk worth a launch of its own: (tiles x matrices) x block rows >= LA_MIN_WORK, i.e. ~40 us of MFMA
+    // work (4.2 MFLOP per tile and block row); below that the step is bound by diag_kernel and the extra launches and
+    // events only cost (lone N = 4096: 2.88 ms without, 3.11 ms with look-ahead everywhere)
+    bool lookahead(int j) const {
+        if (la_stream == nullptr || j < 2 || j >= nrb_steps || split_factor(j, j) <= 1) return false;
+        const long n_tiles = (ncb - j - 1) + ((j + 1 < nrb) ? 1 : 0);
+        return n_tiles * p.Bc * (long)(j - 1) >= LA_MIN_WORK;
+    }
+    double *slab_set(int j) const { return slabs + (size_t)(j & 1) * SLAB_SET_TILES * NB * NB; }
+
+    int launch_split(hipStream_t st, int j, int kb_lo, int kb_hi, int S, int s_off, int S_tot) {
+        const int n_right = ncb - j - 1, n_tiles = n_right + ((j + 1 < nrb) ? 1 : 0);
+        hipLaunchKernelGGL(panel_split_kernel, dim3(xcd_grid(n_tiles * S, p.Bc)), dim3(THREADS), GEMM_LDS, st, p, j, n_right,
+                           n_tiles, kb_lo, kb_hi, S, s_off, S_tot, slab_set(j));
+        BARK_LAUNCH_CHECK();
+        panel_flops += 2.0 * NB * NB * (double)((kb_hi - kb_lo) * NB) * (double)n_tiles * (double)p.Bc;
+        return BARK_OK;
+    }
+    int launch_reduce(hipStream_t st, int j, int S_tot) {
+        const int n_right = ncb - j - 1, n_tiles = n_right + ((j + 1 < nrb) ? 1 : 0);
+        hipLaunchKernelGGL(panel_reduce_kernel, dim3((unsigned)(n_tiles * (NB / RED_ROWS)), (unsigned)p.Bc), dim3(THREADS), 0, st,
+                           p, j, n_right, n_tiles, S_tot, slab_set(j));
+        BARK_LAUNCH_CHECK();
+        return BARK_OK;
+    }
+
     // Block column j of the current chunk (p.Bc matrices): diag(j) || rows(j), then solve(j).  diag(j) and rows(j)
     // both depend only on solve(j-1): diag stays on the caller's stream (dispatched the moment solve(j-1) retires,
     // one slot per CU, 82 KiB of LDS leave room for a row workgroup beside it), the rows go to the helper stream
     // and are joined before solve(j).
+    // Look-ahead (split-K steps, j >= 2): all of T[j,.]'s K range but its last block row only needs rows < j-1, so that
+    // bulk (S slabs) is launched on a third stream right after solve(j-2) and runs beside the whole of step j-1; on
+    // the critical path of step j remain diag(j) || the rank-128 slab of block row j-1, the reduce and the solve.
     int step(int j) {
         hipStream_t s = main, ps = panel;
         const int bc = p.Bc;
@@ -1233,32 +1292,28 @@ struct Sweep {
         const int n_diag = (j + 1 < nrb) ? 1 : 0;
         const int n_tiles = n_right + n_diag;
         int r;
-        int S = 1;  // split-K factor: fill ~SPLITK_SLOTS workgroup slots, >= 1 block row per slab
-        if (splitk && j >= 1 && n_tiles > 0 && n_tiles * bc < SPLITK_SLOTS / 2) {
-            S = SPLITK_SLOTS / (n_tiles * bc);
-            if (S > j) S = j;
-            if (S > SPLITK_MAX) S = SPLITK_MAX;
-        }
+        const bool la = lookahead(j);
+        const int S = la ? split_factor(j, j - 1, LA_SLOTS) : split_factor(j, j);
         // j == 0: with a materialised A the tiles T = A are in place; in fused-Gram sweeps the K = 0 launch writes them
         const bool has_rows = (j >= 1 || fused) && n_tiles > 0;
-        if (has_rows && (r = fork(2 * j))) return r;  // rows(j) wait for everything enqueued so far (solve(j-1))
+        if (has_rows && (r = fork(6 * j))) return r;  // rows(j) wait for everything enqueued so far (solve(j-1))
         if ((r = launch_diag(j))) return r;
         if (has_rows) {
             if (timed) panel_marks.push_back(ev.size());
             if ((r = mark_on(ps))) return r;
-            if (S > 1) {
-                hipLaunchKernelGGL(panel_split_kernel, dim3(xcd_grid(n_tiles * S, bc)), dim3(THREADS), GEMM_LDS, ps, p, j,
-                                   n_right, n_tiles, S, slabs);
-                BARK_LAUNCH_CHECK();
-                hipLaunchKernelGGL(panel_reduce_kernel, dim3((unsigned)(n_tiles * (NB / RED_ROWS)), (unsigned)bc), dim3(THREADS),
-                                   0, ps, p, j, n_right, n_tiles, S, slabs);
-                BARK_LAUNCH_CHECK();
-            } else if ((r = launch_rows(ps, j, n_right, n_tiles))) {
-                return r;
+            if (la) {  // the last block row of the K range; the bulk [0, j-1) was launched after solve(j-2)
+                if ((r = launch_split(ps, j, j - 1, j, 1, S, S + 1))) return r;
+                BARK_HIP_CHECK(hipStreamWaitEvent(ps, res->events[6 * j + 2], 0));  // the bulk slabs of step j
+                if ((r = launch_reduce(ps, j, S + 1))) return r;
+            } else if (S > 1) {
+                if ((r = launch_split(ps, j, 0, j, S, 0, S))) return r;
+                if ((r = launch_reduce(ps, j, S))) return r;
+            } else {
+                if ((r = launch_rows(ps, j, n_right, n_tiles))) return r;
+                panel_flops += 2.0 * NB * NB * (double)(j * NB) * (double)n_tiles * (double)bc;
             }
             if ((r = mark_on(ps))) return r;
-            panel_flops += 2.0 * NB * NB * (double)(j * NB) * (double)n_tiles * (double)bc;
-            if ((r = join(2 * j + 1))) return r;  // solve(j) (and diag(j+1)) need the row's tiles
+            if ((r = join(6 * j + 1))) return r;  // solve(j) (and diag(j+1)) need the row's tiles
         }
         if (n_right > 0) {
             if (timed) solve_marks.push_back(ev.size());
@@ -1269,6 +1324,13 @@ struct Sweep {
             // 18 of the 32 (k-tile, row-tile) products per wave are executed (zero k-tiles of W_j skipped)
             solve_flops += (18.0 / 32.0) * 2.0 * NB * NB * (double)NB * (double)n_right * (double)bc;
         }
+        if (lookahead(j + 2)) {  // rows <= j are final: the bulk of step j+2 can start now
+            const int j2 = j + 2, S2 = split_factor(j2, j2 - 1, LA_SLOTS);
+            BARK_HIP_CHECK(hipEventRecord(res->events[6 * j + 3], s));
+            BARK_HIP_CHECK(hipStreamWaitEvent(la_stream, res->events[6 * j + 3], 0));
+            if ((r = launch_split(la_stream, j2, 0, j2 - 1, S2, 0, S2 + 1))) return r;
+            BARK_HIP_CHECK(hipEventRecord(res->events[6 * j2 + 2], la_stream));
+        }
         return BARK_OK;
     }
 
@@ -1276,6 +1338,7 @@ struct Sweep {
     int report(bark_mll_timing *t, size_t t_begin, size_t t_end, hipStream_t caller) {
         BARK_HIP_CHECK(hipStreamSynchronize(caller));
         if (res && res->helper) BARK_HIP_CHECK(hipStreamSynchronize(res->helper));
+        if (res && res->helper2) BARK_HIP_CHECK(hipStreamSynchronize(res->helper2));
         int r;
         auto span = [&](size_t a, size_t b_, float *acc) -> int {
             float ms = 0.f;
@@ -1358,11 +1421,13 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
     const bool fused = !splitk && C == 0 && (size_t)2 * words * NB * sizeof(uint32_t) <= GEMM_LDS;
     double *slabs = reinterpret_cast<double *>(static_cast<char *>(workspace) + L.off_slab);
     const int nrb = (int)(L.npad / NB), ncb = (int)(L.ncols / NB);
-    if ((rc = ctx_events(ctx, (size_t)2 * nrb))) return rc;
+    if ((rc = ctx_events(ctx, (size_t)6 * nrb + 6))) return rc;
 
     Sweep sw;
     sw.res = ctx;
     sw.nrb = nrb;
+    sw.nrb_steps = nrb;
+    sw.la_stream = ctx->helper2;
     sw.ncb = ncb;
     sw.fused = fused;
     sw.splitk = splitk;
@@ -1545,13 +1610,15 @@ static int leafspace_run(bark_ctx *ctx, const void *packed, const bark_pack_info
     if ((rc = set_lds_limits())) return rc;
     hipStream_t caller = static_cast<hipStream_t>(stream_);
     const int nrb = (int)(g.Rpad / NB);
-    if ((rc = ctx_events(ctx, (size_t)2 * nrb))) return rc;
+    if ((rc = ctx_events(ctx, (size_t)6 * nrb + 6))) return rc;
 
     char *ws = static_cast<char *>(workspace);
     const int ncb = (int)(g.L.ncols / NB);  // posterior: R identity columns appended (M^-1 and w = M^-1 v)
     Sweep sw;
     sw.res = ctx;
     sw.nrb = nrb;
+    sw.nrb_steps = nrb;
+    sw.la_stream = ctx->helper2;
     sw.ncb = ncb;
     sw.fused = false;
     sw.splitk = g.L.splitk;

@@ -32,6 +32,7 @@ int fail(int code, const char *fmt, ...);
 struct bark_ctx {
     int device = 0;
     hipStream_t helper = nullptr;             // dense sweep: row launches beside the diag kernel
+    hipStream_t helper2 = nullptr;            // dense sweep: look-ahead launches of the split-K bulk
     std::vector<hipEvent_t> events;           // fork / join events of the sweep (grown on demand, reused)
     std::vector<hipStream_t> chain_streams;   // multi-chain sampler step: one stream per chain (general shapes)
     std::vector<hipEvent_t> chain_done;

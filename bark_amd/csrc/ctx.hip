@@ -23,6 +23,11 @@ int ctx_events(bark_ctx *ctx, size_t n) {
         BARK_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         BARK_HIP_CHECK(hipStreamCreateWithPriority(&ctx->helper, hipStreamNonBlocking, lo));
     }
+    if (!ctx->helper2) {
+        int lo = 0, hi = 0;
+        BARK_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        BARK_HIP_CHECK(hipStreamCreateWithPriority(&ctx->helper2, hipStreamNonBlocking, lo));
+    }
     while (ctx->events.size() < n) {
         hipEvent_t e;
         BARK_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -84,6 +89,10 @@ void bark_ctx_destroy(bark_ctx *ctx) {
     if (ctx->helper) {
         (void)hipStreamSynchronize(ctx->helper);
         (void)hipStreamDestroy(ctx->helper);
+    }
+    if (ctx->helper2) {
+        (void)hipStreamSynchronize(ctx->helper2);
+        (void)hipStreamDestroy(ctx->helper2);
     }
     for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
     for (hipStream_t s : ctx->chain_streams) {

@@ -17,13 +17,24 @@
 // Bit-exactness: the reference computes `1 / m * count` => fl(fl(1/m) * count); optional
 // `scale *` and `+ (1e-6 + noise)` on the diagonal follow in the reference's order
 // (tree_gps.py:97-100).  The library is built with -ffp-contract=off so no FMA fuses them.
+#include <type_traits>
+
 #include "common.h"
 
 namespace bark {
 namespace {
 
-constexpr int GT = 64;  // output tile edge
+// Output tile of a workgroup: GTR rows x GTC columns, 4096 entries (8 rows x 2 columns per thread).  The kernel is bound
+// by its fp64 stores.  Measured at 16 x 4096^2 (tools/time_gram.py, same box; torch's fill kernel writes 6.3-6.6 TB/s):
+// 64 x 64 tile 6.0 TB/s, 32 x 128 5.9 (6.35 with non-temporal stores), 16 x 256 5.6 (5.8 nt), 8 x 512 5.1 (5.7 nt) —
+// longer row segments per workgroup do NOT help; streaming (nt) stores do once a wave writes full 1 KiB runs.
+#ifndef BARK_GRAM_TC
+#define BARK_GRAM_TC 128
+#endif
+constexpr int GRAM_TC_WIDE = BARK_GRAM_TC;  // build-time tuning constant: 64, 128, 256 or 512
+constexpr int GRAM_TC_NARROW = 64;          // forests whose leaf codes are too wide for the wide tile's LDS strips
 constexpr int GRAM_THREADS = 256;
+static_assert(GRAM_TC_WIDE == 64 || GRAM_TC_WIDE == 128 || GRAM_TC_WIDE == 256 || GRAM_TC_WIDE == 512, "tile width");
 
 struct GramArgs {
     const uint32_t *leaf1;  // (B, W, npad1)
@@ -40,33 +51,39 @@ struct GramArgs {
     int upper_only;    // 1: skip 64-tiles strictly below the 128-block diagonal
 };
 
-template <int REP, bool VEC2>
+template <int REP, bool VEC2, int GTC>
 __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(GramArgs p) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t strips[];  // rows[W][64] | cols[W][64]
+    constexpr int GTR = 8 * (GRAM_THREADS / (GTC / 2));
+    extern __shared__ __attribute__((aligned(16))) uint32_t strips[];  // rows[W][GTR] | cols[W][GTC]
     const int tid = threadIdx.x;
     const int b = blockIdx.z;
-    const int row0 = blockIdx.y * GT, col0 = blockIdx.x * GT;
-    if (p.upper_only && (col0 >> 7) < (row0 >> 7)) return;
+    const int row0 = blockIdx.y * GTR, col0 = blockIdx.x * GTC;
+    if (p.upper_only && ((col0 + GTC - 1) >> 7) < (row0 >> 7)) return;  // wholly below the 128-block diagonal
 
     uint32_t *rows = strips;
-    uint32_t *cols = strips + p.W * GT;
-    for (int e = tid; e < p.W * GT; e += GRAM_THREADS) {
-        const int w = e >> 6, r = e & 63;
-        const int gi = row0 + r, gj = col0 + r;
+    uint32_t *cols = strips + p.W * GTR;
+    for (int e = tid; e < p.W * GTR; e += GRAM_THREADS) {
+        const int w = e / GTR, r = e - w * GTR;
+        const int gi = row0 + r;
         rows[e] = gi < p.npad1 ? p.leaf1[((size_t)b * p.W + w) * p.npad1 + gi] : 0u;
+    }
+    for (int e = tid; e < p.W * GTC; e += GRAM_THREADS) {
+        const int w = e / GTC, r = e - w * GTC;
+        const int gj = col0 + r;
         cols[e] = gj < p.npad2 ? p.leaf2[((size_t)b * p.W + w) * p.npad2 + gj] : 0u;
     }
     __syncthreads();
 
-    // thread -> 8 rows x 2 columns: wave w owns rows 16w..16w+15, half-wave h rows 8h..8h+7 of those, lane pair
-    // column 2*cx.  One store instruction then writes two full 512-byte row segments (32 lanes x 16 B each).
-    const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, cx = lane & 31;
-    const int rloc = wave * 16 + half * 8;
+    // thread -> 8 rows x 2 columns: column pair cx of the tile, row group rg (8 consecutive rows).  A wave's 64 lanes
+    // are consecutive column pairs (GTC >= 128: one full 1 KiB run of a row per store instruction; GTC = 64: two
+    // 512-byte runs of rows 8 apart).
+    const int cx = tid % (GTC / 2), rg = tid / (GTC / 2);
+    const int rloc = rg * 8;
     uint32_t cnt[8][2] = {};  // disagreeing trees (byte codes) / agreeing trees (bit code)
     for (int w = 0; w < p.W; ++w) {
-        const uint4 ra = *reinterpret_cast<const uint4 *>(rows + w * GT + rloc);
-        const uint4 rb = *reinterpret_cast<const uint4 *>(rows + w * GT + rloc + 4);
-        const uint2 cc = *reinterpret_cast<const uint2 *>(cols + w * GT + 2 * cx);
+        const uint4 ra = *reinterpret_cast<const uint4 *>(rows + w * GTR + rloc);
+        const uint4 rb = *reinterpret_cast<const uint4 *>(rows + w * GTR + rloc + 4);
+        const uint2 cc = *reinterpret_cast<const uint2 *>(cols + w * GTC + 2 * cx);
         const uint32_t r[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
@@ -104,7 +121,8 @@ __global__ __launch_bounds__(GRAM_THREADS) void gram_kernel(GramArgs p) {
         }
         double *dst = outb + (size_t)i * p.ld + j0;
         if (VEC2 && j0 + 1 < p.Mout) {
-            *reinterpret_cast<double2 *>(dst) = make_double2(v[0], v[1]);
+            typedef double gram_d2 __attribute__((ext_vector_type(2)));  // streaming store: the matrix is far larger than L2
+            __builtin_nontemporal_store((gram_d2){v[0], v[1]}, reinterpret_cast<gram_d2 *>(dst));
         } else {
             if (j0 < p.Mout) dst[0] = v[0];
             if (j0 + 1 < p.Mout) dst[1] = v[1];
@@ -138,24 +156,32 @@ int launch_gram(const uint32_t *leaf1, int npad1, const uint32_t *leaf2, int npa
     p.pad_identity = pad_identity;
     p.upper_only = upper_only;
     if (B > 65535) return fail(BARK_ERR_ARG, "gram: at most 65535 forests per call");
-    dim3 grid((unsigned)((Mout + GT - 1) / GT), (unsigned)((Nout + GT - 1) / GT), (unsigned)B);
-    const size_t lds = (size_t)2 * p.W * GT * sizeof(uint32_t);
-    if (lds > 64 * 1024) return fail(BARK_ERR_ARG, "gram: too many trees (m=%lld)", (long long)m);
     const bool vec2 = (ld % 2 == 0) && (batch_stride % 2 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    auto launch = [&](auto tc_tag) -> int {
+        constexpr int TC = decltype(tc_tag)::value, TR = 8 * (GRAM_THREADS / (TC / 2));
+        dim3 grid((unsigned)((Mout + TC - 1) / TC), (unsigned)((Nout + TR - 1) / TR), (unsigned)B);
+        const size_t lds = (size_t)p.W * (TR + TC) * sizeof(uint32_t);
+        if (lds > 64 * 1024) return fail(BARK_ERR_ARG, "gram: too many trees (m=%lld)", (long long)m);
 #define BARK_GRAM_LAUNCH(R)                                                                                   \
     do {                                                                                                      \
         if (vec2)                                                                                             \
-            hipLaunchKernelGGL((gram_kernel<R, true>), grid, dim3(GRAM_THREADS), lds, stream, p);             \
+            hipLaunchKernelGGL((gram_kernel<R, true, TC>), grid, dim3(GRAM_THREADS), lds, stream, p);         \
         else                                                                                                  \
-            hipLaunchKernelGGL((gram_kernel<R, false>), grid, dim3(GRAM_THREADS), lds, stream, p);            \
+            hipLaunchKernelGGL((gram_kernel<R, false, TC>), grid, dim3(GRAM_THREADS), lds, stream, p);        \
     } while (0)
-    if (rep == REP_BITS)
-        BARK_GRAM_LAUNCH(REP_BITS);
-    else if (rep == REP_BYTES7)
-        BARK_GRAM_LAUNCH(REP_BYTES7);
-    else
-        BARK_GRAM_LAUNCH(REP_BYTES8);
+        if (rep == REP_BITS)
+            BARK_GRAM_LAUNCH(REP_BITS);
+        else if (rep == REP_BYTES7)
+            BARK_GRAM_LAUNCH(REP_BYTES7);
+        else
+            BARK_GRAM_LAUNCH(REP_BYTES8);
 #undef BARK_GRAM_LAUNCH
+        return BARK_OK;
+    };
+    constexpr int WIDE_TR = 8 * (GRAM_THREADS / (GRAM_TC_WIDE / 2));
+    const bool wide = (size_t)p.W * (WIDE_TR + GRAM_TC_WIDE) * sizeof(uint32_t) <= 64 * 1024;
+    const int rc = wide ? launch(std::integral_constant<int, GRAM_TC_WIDE>{}) : launch(std::integral_constant<int, GRAM_TC_NARROW>{});
+    if (rc) return rc;
     BARK_LAUNCH_CHECK();
     return BARK_OK;
 }
