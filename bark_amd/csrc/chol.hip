@@ -816,14 +816,14 @@ __global__ __launch_bounds__(THREADS, 2) void row_kernel(Mats p, int j, int n_ri
 // One launch over [0, j) is the plain split; the look-ahead schedule (Sweep::step) makes two: the bulk [0, j-1) one
 // step early and the last block row [j-1, j) on the critical path.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(Mats p, int j, int n_right, int n_tiles, int kb_lo, int kb_hi,
-                                                                  int S, int s_off, int S_tot, double *slabs) {
+__global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(Mats p, int j, int n_right, int t_off, int n_tiles, int kb_lo,
+                                                                  int kb_hi, int S, int s_off, int S_tot, double *slabs) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
     int b, ts;
-    if (!xcd_map(blockIdx.x, n_tiles * S, p.Bc, b, ts)) return;
+    if (!xcd_map(blockIdx.x, n_tiles * S, p.Bc, b, ts)) return;  // n_tiles tiles starting at tile t_off of the block row
     const Lane q = lane_of(tid);
-    const int t = ts / S, s = ts - t * S;
+    const int tl = ts / S, s = ts - tl * S, t = t_off + tl;
     const int rb = t < n_right ? j : j + 1, cb = t < n_right ? j + 1 + t : j + 1;
     const int nkb = kb_hi - kb_lo;
     const int kb0 = kb_lo + (int)(((long)nkb * s) / S), kb1 = kb_lo + (int)(((long)nkb * (s + 1)) / S);  // block rows [kb0, kb1)
@@ -831,7 +831,7 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(Mats p, int j, 
     f64x4 acc[4][4];
     zero_acc(acc);
     gemm_kmajor_dma(acc, Ab + (size_t)rb * NB, p.ld, Ab + (size_t)cb * NB, p.ld, (kb1 - kb0) * NB, lds, tid, q);
-    double *slab = slabs + ((size_t)((size_t)b * n_tiles + t) * S_tot + s_off + s) * NB * NB;
+    double *slab = slabs + ((size_t)((size_t)b * n_tiles + tl) * S_tot + s_off + s) * NB * NB;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -843,23 +843,62 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(Mats p, int j, 
 }
 
 constexpr int RED_ROWS = 8;  // rows of a 128 x 128 tile per panel_reduce_kernel workgroup (4 doubles per thread)
-__global__ __launch_bounds__(THREADS) void panel_reduce_kernel(Mats p, int j, int n_right, int n_tiles, int S,
+// T = A - sum of the tile's S slabs (fixed order: bit-reproducible) for the n_tiles tiles from t_off on.
+// GEN == 0: A is read from (and T written to) the materialised matrix; GEN == 1 + LeafRep: A is generated from the
+// leaf codes exactly as form_tile does (MLL-only sweeps never materialise the Gram matrix).
+template <int GEN>
+__global__ __launch_bounds__(THREADS) void panel_reduce_kernel(Mats p, int j, int n_right, int t_off, int n_tiles, int S,
                                                                const double *slabs) {
-    const int t = blockIdx.x / (NB / RED_ROWS), part = blockIdx.x % (NB / RED_ROWS), b = blockIdx.y;
+    const int tl = blockIdx.x / (NB / RED_ROWS), part = blockIdx.x % (NB / RED_ROWS), b = blockIdx.y;
+    const int t = t_off + tl;
     const int rb = t < n_right ? j : j + 1, cb = t < n_right ? j + 1 + t : j + 1;
     const int e = part * RED_ROWS * NB + 4 * threadIdx.x;  // four consecutive entries of one tile row
-    const double *slab = slabs + (size_t)((size_t)b * n_tiles + t) * S * NB * NB + e;
+    const double *slab = slabs + (size_t)((size_t)b * n_tiles + tl) * S * NB * NB + e;
     f64x2 s0 = {0.0, 0.0}, s1 = {0.0, 0.0};
 #pragma unroll 4
-    for (int s = 0; s < S; ++s) {  // fixed order: bit-reproducible
+    for (int s = 0; s < S; ++s) {
         const f64x2 *src = reinterpret_cast<const f64x2 *>(slab + (size_t)s * NB * NB);
         s0 += src[0];
         s1 += src[1];
     }
-    f64x2 *dst = reinterpret_cast<f64x2 *>(p.A + (size_t)b * p.bstride + ((size_t)rb * NB + (e >> 7)) * p.ld +
-                                       (size_t)cb * NB + (e & (NB - 1)));
-    dst[0] -= s0;
-    dst[1] -= s1;
+    const int r = e >> 7, c0 = e & (NB - 1);
+    f64x2 *dst = reinterpret_cast<f64x2 *>(p.A + (size_t)b * p.bstride + ((size_t)rb * NB + r) * p.ld + (size_t)cb * NB + c0);
+    if (GEN == 0) {
+        dst[0] -= s0;
+        dst[1] -= s1;
+        return;
+    }
+    const int npad = p.nrb * NB, gi = rb * NB + r, gj0 = cb * NB + c0;
+    const uint32_t *lb = p.leafx + (size_t)b * p.nW * npad;
+    uint32_t cnt[4] = {0, 0, 0, 0};
+    for (int w = 0; w < p.nW; ++w) {
+        const uint32_t rw = lb[(size_t)w * npad + gi];
+        const uint4 cw = *reinterpret_cast<const uint4 *>(lb + (size_t)w * npad + gj0);
+        cnt[0] += code_count<(GEN > 0 ? GEN - 1 : 0)>(rw, cw.x);
+        cnt[1] += code_count<(GEN > 0 ? GEN - 1 : 0)>(rw, cw.y);
+        cnt[2] += code_count<(GEN > 0 ? GEN - 1 : 0)>(rw, cw.z);
+        cnt[3] += code_count<(GEN > 0 ? GEN - 1 : 0)>(rw, cw.w);
+    }
+    const double inv_m = 1.0 / (double)p.m;
+    const bool has_scale = p.scale != nullptr, has_shift = p.shift != nullptr;
+    const double sc = has_scale ? p.scale[b] : 1.0, sh = has_shift ? p.shift[b] : 0.0, jitter = 1e-6 + p.noise[b];
+    double val[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gj = gj0 + i;
+        double v;
+        if (gi < p.N && gj < p.N) {
+            v = inv_m * (double)agree_count<(GEN > 0 ? GEN - 1 : 0)>(cnt[i], p.m);
+            if (has_shift) v = v - sh;
+            if (has_scale) v = sc * v;
+            if (gi == gj) v = v + jitter;
+        } else {
+            v = gi == gj ? 1.0 : 0.0;  // identity padding
+        }
+        val[i] = v;
+    }
+    dst[0] = (f64x2){val[0], val[1]} - s0;
+    dst[1] = (f64x2){val[2], val[3]} - s1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1087,6 +1126,10 @@ constexpr int LA_SLOTS = BARK_LA_SLOTS;
 #define BARK_LA_MIN_WORK 600
 #endif
 constexpr long LA_MIN_WORK = BARK_LA_MIN_WORK;
+#ifndef BARK_TAIL_MAX_WGS
+#define BARK_TAIL_MAX_WGS 192
+#endif
+constexpr long TAIL_MAX_WGS = BARK_TAIL_MAX_WGS;  // ragged_tail: largest last round (workgroups) that is split over K
 #ifndef BARK_SPLITK_LAYOUT_MAX_TILES
 #define BARK_SPLITK_LAYOUT_MAX_TILES 1100
 #endif
@@ -1127,7 +1170,7 @@ Layout make_layout(int64_t N, int64_t C, int64_t m, int64_t Bc) {
     L.splitk = Bc * (L.ncols / NB) < SPLITK_LAYOUT_MAX_TILES && L.npad / NB >= 4;
     // two slab sets (look-ahead: the bulk of step j+1 is accumulated while step j is reduced); a split step has fewer
     // than SPLITK_SLOTS / 2 tiles x matrices, S of at most SPLITK_SLOTS / that, plus one slab for the last block row
-    if (L.splitk) o = align256(o + (size_t)2 * SLAB_SET_TILES * NB * NB * sizeof(double));
+    o = align256(o + (size_t)2 * SLAB_SET_TILES * NB * NB * sizeof(double));  // every chunk: ragged last rounds split K too
     L.total = o;
     return L;
 }
@@ -1262,20 +1305,54 @@ struct Sweep {
     }
     double *slab_set(int j) const { return slabs + (size_t)(j & 1) * SLAB_SET_TILES * NB * NB; }
 
-    int launch_split(hipStream_t st, int j, int kb_lo, int kb_hi, int S, int s_off, int S_tot) {
-        const int n_right = ncb - j - 1, n_tiles = n_right + ((j + 1 < nrb) ? 1 : 0);
-        hipLaunchKernelGGL(panel_split_kernel, dim3(xcd_grid(n_tiles * S, p.Bc)), dim3(THREADS), GEMM_LDS, st, p, j, n_right,
-                           n_tiles, kb_lo, kb_hi, S, s_off, S_tot, slab_set(j));
+    // split-K over block rows [kb_lo, kb_hi) for the tiles [t_off, t_off + nt) of block row j (nt < 0: all of them)
+    int launch_split(hipStream_t st, int j, int kb_lo, int kb_hi, int S, int s_off, int S_tot, int t_off = 0, int nt = -1) {
+        const int n_right = ncb - j - 1, n_all = n_right + ((j + 1 < nrb) ? 1 : 0);
+        if (nt < 0) nt = n_all - t_off;
+        hipLaunchKernelGGL(panel_split_kernel, dim3(xcd_grid(nt * S, p.Bc)), dim3(THREADS), GEMM_LDS, st, p, j, n_right, t_off, nt,
+                           kb_lo, kb_hi, S, s_off, S_tot, slab_set(j));
         BARK_LAUNCH_CHECK();
-        panel_flops += 2.0 * NB * NB * (double)((kb_hi - kb_lo) * NB) * (double)n_tiles * (double)p.Bc;
+        panel_flops += 2.0 * NB * NB * (double)((kb_hi - kb_lo) * NB) * (double)nt * (double)p.Bc;
         return BARK_OK;
     }
-    int launch_reduce(hipStream_t st, int j, int S_tot) {
-        const int n_right = ncb - j - 1, n_tiles = n_right + ((j + 1 < nrb) ? 1 : 0);
-        hipLaunchKernelGGL(panel_reduce_kernel, dim3((unsigned)(n_tiles * (NB / RED_ROWS)), (unsigned)p.Bc), dim3(THREADS), 0, st,
-                           p, j, n_right, n_tiles, S_tot, slab_set(j));
+    int launch_reduce(hipStream_t st, int j, int S_tot, int t_off = 0, int nt = -1) {
+        const int n_right = ncb - j - 1, n_all = n_right + ((j + 1 < nrb) ? 1 : 0);
+        if (nt < 0) nt = n_all - t_off;
+        const dim3 g((unsigned)(nt * (NB / RED_ROWS)), (unsigned)p.Bc), blk(THREADS);
+        if (!fused)
+            hipLaunchKernelGGL(panel_reduce_kernel<0>, g, blk, 0, st, p, j, n_right, t_off, nt, S_tot, slab_set(j));
+        else if (rep == REP_BITS)
+            hipLaunchKernelGGL(panel_reduce_kernel<1 + REP_BITS>, g, blk, 0, st, p, j, n_right, t_off, nt, S_tot, slab_set(j));
+        else if (rep == REP_BYTES7)
+            hipLaunchKernelGGL(panel_reduce_kernel<1 + REP_BYTES7>, g, blk, 0, st, p, j, n_right, t_off, nt, S_tot, slab_set(j));
+        else
+            hipLaunchKernelGGL(panel_reduce_kernel<1 + REP_BYTES8>, g, blk, 0, st, p, j, n_right, t_off, nt, S_tot, slab_set(j));
         BARK_LAUNCH_CHECK();
         return BARK_OK;
+    }
+    // Ragged last round (chunks that are NOT in the split-K layout): n_tiles x Bc workgroups rarely fill whole rounds
+    // of the chip's SPLITK_SLOTS slots, and the stragglers of the last round run one per CU for a full tile time
+    // (measured at B = 64: up to 35 % per step when one tile in nine is left over).  The tiles beyond the last full
+    // round are split over K instead, so that they finish in a fraction of a round: -> first tile of the tail and its
+    // split factor (tail == n_tiles: nothing to split).
+    void ragged_tail(int j, int n_tiles, int &tail, int &S) const {
+        tail = n_tiles;
+        S = 1;
+        if (splitk || j < 2 || n_tiles <= 0) return;
+        const long bc = p.Bc, slots = SPLITK_SLOTS;
+        const long rounds = (n_tiles * bc) / slots;
+        const long n_plain = rounds * slots / bc;  // tiles that fill whole rounds
+        if (n_plain * bc != rounds * slots) return;  // rounds do not end on a tile boundary (Bc does not divide the slots)
+        const long m = n_tiles - n_plain;
+        // worth it for a sparse last round only (a slab round trip and two more launches): measured at N = 4096,
+        // B = 64 27.8 -> 27.0 ms, B = 48 22.8 -> 21.8 ms; a half-filled last round (B = 256, odd tile counts) gains nothing
+        if (m <= 0 || m * bc > TAIL_MAX_WGS) return;
+        long s = slots / (m * bc);
+        if (s > j) s = j;
+        if (s > SPLITK_MAX) s = SPLITK_MAX;
+        if (s < 2) return;
+        tail = (int)n_plain;
+        S = (int)s;
     }
 
     // Block column j of the current chunk (p.Bc matrices): diag(j) || rows(j), then solve(j).  diag(j) and rows(j)
@@ -1309,8 +1386,16 @@ struct Sweep {
                 if ((r = launch_split(ps, j, 0, j, S, 0, S))) return r;
                 if ((r = launch_reduce(ps, j, S))) return r;
             } else {
-                if ((r = launch_rows(ps, j, n_right, n_tiles))) return r;
-                panel_flops += 2.0 * NB * NB * (double)(j * NB) * (double)n_tiles * (double)bc;
+                int tail, St;
+                ragged_tail(j, n_tiles, tail, St);
+                if (tail > 0) {
+                    if ((r = launch_rows(ps, j, n_right, tail))) return r;
+                    panel_flops += 2.0 * NB * NB * (double)(j * NB) * (double)tail * (double)bc;
+                }
+                if (tail < n_tiles) {
+                    if ((r = launch_split(ps, j, 0, j, St, 0, St, tail, n_tiles - tail))) return r;
+                    if ((r = launch_reduce(ps, j, St, tail, n_tiles - tail))) return r;
+                }
             }
             if ((r = mark_on(ps))) return r;
             if ((r = join(6 * j + 1))) return r;  // solve(j) (and diag(j+1)) need the row's tiles

@@ -590,8 +590,10 @@ def test_single_large_matrix_split_k_path(B):
 
 def test_many_small_matrices_and_chunk_invariance(B):
     """B = 288 forests at N = 700 (6 block rows): a filled chip of small matrices against the oracle's LU route, and
-    the same forests factorised 192 at a time: without split-K a forest's result does not depend on the chunk it
-    sits in (identical bits).  Also with candidates (materialised A, candidate columns carry no right-hand side)."""
+    the same forests factorised 192 at a time.  Which tiles of a step take the split-K route (ragged last round of
+    workgroups) depends on the chunk size, so results agree to rounding (1e-12 relative), not bit for bit; for a
+    given chunk size they are reproducible exactly.  Also with candidates (materialised A, candidate columns carry
+    no right-hand side)."""
     nb, N = 288, 700
     X, y, bounds, ft = B.syn.mixed_problem(N, seed=31)
     F = B.syn.sample_prior_forests(nb, 50, bounds, ft, seed=310)
@@ -602,7 +604,8 @@ def test_many_small_matrices_and_chunk_invariance(B):
     fused = B.fit.batched_mll(F, noise, scale, X, y, ft, include_scale=True, include_2pi=True)
     assert np.allclose(fused[sub], want, rtol=MLL_RTOL, atol=MLL_ATOL), np.abs(fused[sub] - want).max()
     small = B.fit.batched_mll(F, noise, scale, X, y, ft, include_scale=True, include_2pi=True, chunk=192)
-    assert np.array_equal(fused, small)
+    assert np.allclose(fused, small, rtol=1e-12, atol=0.0)
+    assert np.array_equal(small, B.fit.batched_mll(F, noise, scale, X, y, ft, include_scale=True, include_2pi=True, chunk=192))
     # ragged last chunk, other convention
     part = B.fit.batched_mll(F, noise, None, X, y, ft, include_scale=False, include_2pi=True, chunk=200)
     want2 = B.orc.batched_mll(F[sub], noise[sub], None, X, y, ft, include_scale=False, include_2pi=True)
@@ -615,7 +618,7 @@ def test_many_small_matrices_and_chunk_invariance(B):
     from bark_amd.fitting.mll import _run
     import bark_amd._lib as L
     _, mu8, var8 = _run(F, noise, scale, X, y, ft, L.MLL_INCLUDE_SCALE, cand=cand, chunk=200)
-    assert np.array_equal(mu8.cpu().numpy(), mu) and np.array_equal(var8.cpu().numpy(), var)
+    assert np.allclose(mu8.cpu().numpy(), mu, rtol=1e-10, atol=1e-11) and np.allclose(var8.cpu().numpy(), var, rtol=1e-10, atol=1e-11)
 
 
 def test_leafspace_mll_equals_dense_and_reference(B):
