@@ -109,6 +109,26 @@ def launch(args) -> int:
 # ---------------------------------------------------------------------------------------------
 # helpers (workers)
 # ---------------------------------------------------------------------------------------------
+def host_cores() -> int:
+    """Cores this process can really run on: CPU affinity capped by the cgroup CPU quota (cpu.max)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def csrc_digest() -> str:
     """Content hash of the kernel sources (there is no .git on the GPU box): ties a committed PMC profile to a build."""
     h = hashlib.sha256()
@@ -343,8 +363,24 @@ def worker(args) -> int:
 
         kw = dict(rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
         if backend == "nccl":
-            kw["device_id"] = torch.device("cuda", dev_index)
-        dist.init_process_group(backend, **kw)
+            try:  # RCCL over xGMI; one tiny collective proves the communicator before the timed region
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), **kw)
+                probe = torch.ones(1, device=torch.device("cuda", dev_index))
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                assert int(probe.item()) == world
+            except Exception as exc:  # an unusable RCCL setup must not cost the scaling measurement: the exchange is 8 B
+                # per sample, so host staging over gloo changes nothing measurable.  Every rank sees the same failure.
+                print(f"[bench rank {rank}] RCCL unavailable ({exc!r}); falling back to gloo for the MLL gather", file=sys.stderr)
+                try:
+                    dist.destroy_process_group()
+                except Exception:
+                    pass
+                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17)
+                backend = "gloo"
+                dist.init_process_group("gloo", **kw)
+        else:
+            dist.init_process_group(backend, **kw)
 
     from bark_amd import _lib
     from bark_amd.distributed import gather_mll, shard_range
@@ -428,7 +464,7 @@ def worker(args) -> int:
                         ("c3: N=%d d=%d m=%d, %d prior forest samples per GPU (BASELINE configs[2]; sharding of "
                          "configs[3])" % (N, d, m, B)) + ", noise U[0.05,0.15), mcmc_record_mll convention",
             "N": N, "d": d, "trees": m, "forests_per_gpu": B, "forests_total": total, "chunk": wl.Bc,
-            "parallelism": "samples/%d" % world, "launched_by": "bench.py" if os.environ.get("BARK_BENCH_WORKER") else "external",
+            "parallelism": "samples/%d" % world, "collective_backend": (backend if world > 1 else None), "launched_by": "bench.py" if os.environ.get("BARK_BENCH_WORKER") else "external",
             "timed_path": "production (timing=NULL, no host sync inside the library)",
         },
         "roofline": {
@@ -583,15 +619,24 @@ def extras(args, wl, result, mll_host):
     if args.cpu_sample > 0:
         from oracle import oracle as orc
 
-        cores = len(os.sched_getaffinity(0))
+        cores = host_cores()
         ns = min(args.cpu_sample, B)
         F, noise = wl.forests, wl.noise
+        try:  # LAPACK threads = the cores this process may really use (a pool sized to every core of a shared host
+            # oversubscribes the container's CPU quota and runs slower than one thread)
+            from threadpoolctl import threadpool_limits
+
+            limit = threadpool_limits(limits=cores)
+        except Exception:  # pragma: no cover
+            limit = None
         t1 = time.perf_counter()
         ref = orc.batched_mll(F[:ns], noise[:ns], None, wl.X, wl.y, wl.ft, include_scale=False, include_2pi=True)
         cpu_s = time.perf_counter() - t1
         t2 = time.perf_counter()
         orc.batched_mll(F[:ns], noise[:ns], None, wl.X, wl.y, wl.ft, include_scale=False, include_2pi=True, cholesky=True)
         chol_s = time.perf_counter() - t2
+        if limit is not None:
+            limit.restore_original_limits()
         rel = float(np.max(np.abs(mll_host[:ns] - ref) / np.abs(ref)))
         assert np.allclose(mll_host[:ns], ref, rtol=1e-9, atol=1e-8), (mll_host[:ns], ref)
         single = None
@@ -612,7 +657,7 @@ def extras(args, wl, result, mll_host):
             "cores": cores,
             "kind": "port",
             "sample": "%d of the %d forest samples of this workload (N=%d): C leaf walk + N*N*m compare-count Gram "
-                      "(1 thread, as the reference) + numpy.linalg.inv + slogdet (LAPACK on all %d cores), %.1f s"
+                      "(1 thread, as the reference) + numpy.linalg.inv + slogdet (LAPACK on the %d usable cores), %.1f s"
                       % (ns, B, N, cores, cpu_s),
             "cholesky_variant_evals_per_s": ns / chol_s,
             "single_thread": single,
