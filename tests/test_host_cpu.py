@@ -234,12 +234,37 @@ def test_committed_bench_line_follows_the_contract():
     assert r["n_gpus"] >= 1 and r["steps"] >= 1 and r["warmup"] >= 0 and r["value"] > 0 and r["ms_per_step"] > 0
     assert "workload" in r["config"] and "model" not in r["config"]
     assert abs(r["value"] - r["config"]["forests_per_gpu"] * r["n_gpus"] / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
+    assert r["config"]["timed_path"].startswith("production")  # timing = NULL: no host sync inside the library
     roof = r["roofline"]
     assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s")
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and 0 < roof["frac"] < 1
     assert roof["traffic"] is None or roof["traffic"] > 0
+    # `achieved` is the algorithmic flops over the event-timed call, which cannot be shorter than... nor much longer than a step
+    assert 0.9 * r["ms_per_step"] < roof["call_ms"] <= 1.001 * r["ms_per_step"]
+    g = roof["gram_kernel"]
+    assert g["bound"] == "hbm" and 0 < g["frac"] < 1
     cpu = r["cpu_baseline"]
     assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
+    assert cpu["single_thread"]["cores"] == 1 and cpu["single_thread"]["value"] > 0
+    names = " ".join(c["config"] for c in r["configs"])
+    assert "c2" in names and "c4" in names and "c5 MLL" in names and "c5 posterior" in names
+
+
+def test_committed_hbm_profile_names_its_build():
+    """roofline.traffic is only quoted from a PMC profile that records the kernel-source digest and workload it was taken on."""
+    import glob
+    import json
+
+    import bench
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r02", "*hbm_counters*.json")))
+    assert files
+    meta = json.load(open(files[-1]))["meta"]
+    assert set(("N", "B", "m", "csrc_digest", "steps_profiled", "sweep_kernels", "command")) <= set(meta)
+    assert bench.hbm_traffic_from_profile(1, 2, 3) is None  # another workload: never a stale figure
+    t = bench.hbm_traffic_from_profile(meta["N"], meta["B"], meta["m"])
+    assert t is None or (t["csrc_digest"] == bench.csrc_digest() and t["bytes_per_step"] > 1e10)
 
 
 def test_packer_walk_bound_is_the_longest_path_when_a_node_has_two_parents():

@@ -1,0 +1,20 @@
+#!/bin/bash
+# usage (on the GPU box, repo root): tools/collect_profiles.sh   -> gpurun_out/prof_r02/*  (copy what is wanted into profiles/rNN/)
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_r02
+mkdir -p $OUT
+export PYTHONPATH=$ROOT
+python3 bench.py > $OUT/bench_c3_final.json 2> $OUT/bench.err || { echo bench failed; tail -5 $OUT/bench.err; exit 1; }
+for spec in "c3 4096 256 2" "b64 4096 64 3" "b16 4096 16 3" "b1 4096 1 5" "c2 1024 1 10" "c5 16384 1 2" "c5_posterior 16384 1 1 10000"; do
+  set -- $spec; label=$1; shift
+  tools/kernel_trace.sh $label product "$@" > /dev/null || exit 1
+  cp gpurun_out/trace_$label.txt $OUT/trace_$label.txt
+done
+tools/hbm_counters.sh 4096 256 1 > $OUT/hbm_counters.log || exit 1
+cp gpurun_out/hbm_counters.json $OUT/bench_c3_hbm_counters.json
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/ks
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o t -- python3 $ROOT/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-configs > $OUT/bench_under_rocprof.json 2>/dev/null || { echo stats run failed; exit 1; }
+f=$(find /tmp/ks -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && cp $f $OUT/bench_c3_kernel_stats_final.csv
+ls -la $OUT
