@@ -7,7 +7,8 @@ Same three functions, same signatures:
     mll(K_inv, K_logdet, y)                                  quick_inverse.py:37-38
 
 numpy in -> numpy out; pass CUDA `torch` tensors to keep K_inv resident in HBM between the many
-updates of an MCMC step (bark_sampler.py:233-257) — then device tensors / 0-d tensors come back.
+updates of an MCMC step (bark_sampler.py:233-257) — then K_inv comes back as a device tensor; the scalar results
+(log-determinant, MLL) are host floats, as in the reference (the sampler branches on them).
 The kernels (csrc/lowrank.hip) are two streaming passes over K_inv around r x r algebra.
 """
 
@@ -63,9 +64,7 @@ def low_rank_inv_update(K_inv, U, subtract: bool = False, *, assume_symmetric: b
 def low_rank_det_update(K_inv, U, K_logdet, subtract: bool = False):
     """quick_inverse.py:24-33: K_logdet + log|det(I + mul U' K_inv U)|."""
     _, det = _update(K_inv, U, subtract, False, True)
-    if _is_torch(K_inv):
-        return K_logdet + det[0]
-    return K_logdet + float(det.item())
+    return float(K_logdet) + float(det.item())  # a host scalar, as in the reference (its caller branches on it)
 
 
 def mll(K_inv, K_logdet, y) -> float:
@@ -79,6 +78,4 @@ def mll(K_inv, K_logdet, y) -> float:
         raise ValueError(f"K_inv is {tuple(Kd.shape)}, y has {N} rows")
     out = torch.empty(1, dtype=torch.float64, device=Kd.device)
     _lib.check(_lib.lib().bark_quadform_hip(_lib.ptr(Kd), _lib.ptr(yd), N, _lib.ptr(out), _lib.stream_ptr()))
-    if _is_torch(K_inv):
-        return 0.5 * (-out[0] - K_logdet)
     return 0.5 * (-float(out.item()) - float(K_logdet))

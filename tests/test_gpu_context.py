@@ -223,3 +223,58 @@ def test_node_with_two_parents_walks_like_the_reference(env):
     want = env.orc.pass_through_forest(nodes, X, ft)
     assert np.array_equal(bf.pass_through_forest(nodes, X, ft), want)
     assert np.array_equal(bf.forest_gram_matrix(nodes, X, X, ft), env.orc.forest_gram_matrix(nodes, X, X, ft))
+
+
+def test_product_path_launches_no_torch_compute_kernels(env):
+    """torch is the device-memory container of the product, not its arithmetic: a pass over the API surface under the
+    profiler must show only bark:: kernels and runtime copies / fills — no at::native::* elementwise, reduction or
+    indexing kernels and no rocBLAS."""
+    from torch.profiler import ProfilerActivity, profile
+
+    import bark_amd.tree_kernels as tk
+    from bark_amd.fitting import quick_inverse as qi
+
+    torch, bf, fit, syn = env.torch, env.bf, env.fit, env.syn
+    N, C, nb, m = 300, 70, 4, 12
+    X, y, bounds, ft = syn.mixed_problem(N, seed=1)
+    cand = syn.mixed_problem(C, seed=2)[0]
+    F = syn.sample_prior_forests(nb, m, bounds, ft, seed=3)
+    noise, scale = np.linspace(0.05, 0.2, nb), np.linspace(0.8, 1.2, nb)
+    Xd, cd = torch.from_numpy(X).cuda(), torch.from_numpy(cand).cuda()
+    rng = np.random.default_rng(0)
+
+    def surface():
+        bf.pass_through_forest(F[0], Xd, ft)
+        U = bf.get_leaf_vectors(F[0][0], Xd, ft)
+        bf.batched_forest_gram_matrix(F, Xd, Xd, ft)
+        bf.batched_forest_gram_matrix_no_null(F, X, X, ft)
+        fit.batched_mll(F, noise, scale, Xd, y, ft, include_scale=True, include_2pi=False, return_device=True)
+        fit.batched_mll(F, noise, None, X, y, ft, include_scale=False, include_2pi=True, method="leafspace")
+        mu, var = tk.forest_predict((F, noise, scale), (Xd, y), cd, ft)
+        tk.forest_predict((F, noise, scale), (X, y), cand, ft, diag=False)
+        tk.mixture_of_gaussians_as_normal(mu, var)
+        K_inv, _, logdet = fit.batched_kernel_inverse(F, noise, scale, Xd, y, ft, no_null=False, return_device=True)
+        fit.batched_kernel_inverse(F[:1], noise[:1], scale[:1], X, y, ft, no_null=True)
+        qi.low_rank_inv_update(K_inv[0], U, subtract=False, assume_symmetric=True)
+        qi.low_rank_det_update(K_inv[0], U, float(logdet[0].item()))
+        qi.mll(K_inv[0], float(logdet[0].item()), y)
+        st = fit.ChainState.from_forest(F[0], 0.1, 1.0, Xd, y, ft)
+        st.propose_tree(F[0][0], F[1][0], Xd, ft, 1.0, m)
+        st.accept()
+        st.propose(bf.get_leaf_vectors(F[0][1], X, ft), bf.get_leaf_vectors(F[1][1], X, ft))
+        st.accept()
+        st.propose_noise_scale(F[0], 0.12, 1.1, Xd, ft)
+        st.accept()
+        cb = fit.ChainBatch.from_forests(F[:2], noise[:2], scale[:2], Xd, y, ft)
+        cb.propose_trees(F[:2, 0], F[2:4, 0], Xd, ft, scale[:2], m)
+        cb.accept([True, False])
+        cb.sweep_trees(F[:2, :6], F[2:4, :6], rng.normal(size=(2, 6)), np.log(rng.uniform(size=(2, 6))), Xd, ft, scale[:2], m)
+        torch.cuda.synchronize()
+
+    surface()  # warm-up: library load, contexts
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        surface()
+    names = [e.key for e in prof.key_averages()]
+    assert any("bark" in n for n in names), names
+    foreign = [n for n in names if "at::native" in n or "rocblas" in n.lower() or "Cijk" in n]
+    assert not foreign, foreign

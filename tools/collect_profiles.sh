@@ -13,6 +13,9 @@ done
 tools/hbm_counters.sh 4096 256 1 > $OUT/hbm_counters.log || exit 1
 cp gpurun_out/hbm_counters.json $OUT/bench_c3_hbm_counters.json
 cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/kt_api
+timeout -k 10 300 rocprofv3 --kernel-trace -d /tmp/kt_api -o t -- python3 $ROOT/tools/profile_api_surface.py > /dev/null 2>&1 || { echo api trace failed; exit 1; }
+python3 $ROOT/tools/ab/kstats.py /tmp/kt_api > $OUT/api_surface_kernels.txt
 rm -rf /tmp/ks
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o t -- python3 $ROOT/bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-configs > $OUT/bench_under_rocprof.json 2>/dev/null || { echo stats run failed; exit 1; }
 f=$(find /tmp/ks -name "*kernel_stats.csv" | head -1)
