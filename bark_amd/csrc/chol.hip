@@ -1350,7 +1350,7 @@ struct Sweep {
         long s = slots / (m * bc);
         if (s > j) s = j;
         if (s > SPLITK_MAX) s = SPLITK_MAX;
-        if (s < 2) return;
+        if (s < 3) return;  // a 2-way split of a third-filled round measured slower than leaving it (B = 64, j = 5, 13, 21)
         tail = (int)n_plain;
         S = (int)s;
     }
