@@ -290,3 +290,28 @@ def test_packer_walk_bound_is_the_longest_path_when_a_node_has_two_parents():
     assert info.max_depth == 4  # 0 -> 2 -> 4 -> 3 -> leaf
     # the oracle follows the pointers like the reference: x = 0.55 takes the deep path and ends on leaf 6
     assert orc.pass_through_forest(nodes, np.array([[0.55], [0.2], [0.05]]), ft)[:, 0].tolist() == [6, 6, 5]
+
+
+def test_context_api_without_a_gpu_fails_with_a_status_not_a_crash():
+    """bark_ctx_* are plain C calls: on a host without a GPU creation reports an error code and message; destroy(NULL)
+    and the size query on NULL are harmless.  (On a GPU box creation succeeds and the context is destroyed again.)"""
+    import ctypes
+
+    from bark_amd import _lib
+
+    lib = _lib.lib()
+    h = ctypes.c_void_p()
+    rc = lib.bark_ctx_create(0, ctypes.byref(h))
+    if rc == 0:
+        assert h.value
+        lib.bark_ctx_destroy(h)
+    else:
+        assert not h.value and lib.bark_last_error() != b""
+    assert lib.bark_ctx_create(0, None) != 0
+    lib.bark_ctx_destroy(None)
+    assert lib.bark_ctx_workspace_bytes(None) == 0
+    # entry points refuse a null context before touching anything else
+    assert lib.bark_leaf_indices_hip(None, None, None, None, 1, 1, None, None) == _lib.BARK_ERR_ARG
+    assert b"bark_ctx" in lib.bark_last_error()
+    assert lib.bark_mll_batched_hip(None, None, None, None, 1, 1, None, None, None, None, 0, None, 0, None, None, None, None, None,
+                                    None, 0, 1, None, None) == _lib.BARK_ERR_ARG
