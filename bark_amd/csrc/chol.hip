@@ -1176,6 +1176,15 @@ Layout make_layout(int64_t N, int64_t C, int64_t m, int64_t Bc) {
 }
 
 constexpr size_t DIAG_LDS = (size_t)(NBLK * SB * SB + 4 * SB * TS + 2 * NB + 8) * sizeof(double);
+// With few matrices resident the diag workgroup IS the critical path of the sweep, and a split-K / row workgroup that
+// lands on its CU stretches it from 52 to 62-77 us (kernel timeline of a lone N = 4096 matrix).  Asking for the whole
+// 160 KiB of LDS keeps the CU to itself (lone N = 4096: 2.83 -> 2.59 ms; neutral from 8 matrices on, harmful at 64:
+// 26.7 -> 27.5 ms); with many matrices the kernel is hidden and must share (DIAG_LDS).
+#ifndef BARK_DIAG_EXCLUSIVE_MAX_BC
+#define BARK_DIAG_EXCLUSIVE_MAX_BC 16
+#endif
+constexpr size_t DIAG_LDS_EXCLUSIVE = 160 * 1024;
+constexpr int DIAG_EXCLUSIVE_MAX_BC = BARK_DIAG_EXCLUSIVE_MAX_BC;
 constexpr size_t GEMM_LDS = (size_t)GEMM_LDS_DOUBLES * sizeof(double);
 static_assert(DIAG_LDS >= GEMM_LDS, "diag kernel reuses its LDS for the K=128 GEMM stage");
 
@@ -1198,7 +1207,7 @@ int set_lds_limits() {
         auto set = [](const void *fn, size_t bytes) {
             return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         };
-        hipError_t e = set(reinterpret_cast<const void *>(diag_kernel), DIAG_LDS);
+        hipError_t e = set(reinterpret_cast<const void *>(diag_kernel), DIAG_LDS_EXCLUSIVE);
         if (e == hipSuccess) e = set(reinterpret_cast<const void *>(row_kernel<0>), GEMM_LDS);
         if (e == hipSuccess) e = set(reinterpret_cast<const void *>(row_kernel<1>), GEMM_LDS);
         if (e == hipSuccess) e = set(reinterpret_cast<const void *>(row_kernel<2>), GEMM_LDS);
@@ -1264,7 +1273,8 @@ struct Sweep {
         int r;
         if (timed) diag_marks.push_back(ev.size());
         if ((r = mark_on(main))) return r;
-        hipLaunchKernelGGL(diag_kernel, dim3((unsigned)p.Bc), dim3(THREADS), DIAG_LDS, main, p, j);
+        hipLaunchKernelGGL(diag_kernel, dim3((unsigned)p.Bc), dim3(THREADS), p.Bc <= DIAG_EXCLUSIVE_MAX_BC ? DIAG_LDS_EXCLUSIVE : DIAG_LDS,
+                           main, p, j);
         BARK_LAUNCH_CHECK();
         return mark_on(main);
     }
