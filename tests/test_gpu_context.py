@@ -120,6 +120,22 @@ def test_sweep_is_hipgraph_capturable(env):
     g2.replay()
     torch.cuda.synchronize()
     assert bool((wl2.mll_d == eager2).all())
+    # and the split-K look-ahead schedule (third stream: the bulk of step j+2 forks after solve(j) and joins two steps later)
+    wl3 = bench.Workload(4096, 8, 50, 8, seed_base=4096, rank_offset=0)  # (tiles x matrices) x block rows >= 600 from step 5 on
+    wl3.run()
+    torch.cuda.synchronize()
+    eager3 = wl3.mll_d.clone()
+    g3 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g3):
+        wl3.stream = env.lib.stream_ptr()
+        wl3.run()
+    wl3.mll_d.zero_()
+    g3.replay()
+    g3.replay()
+    torch.cuda.synchronize()
+    assert bool((wl3.mll_d == eager3).all()) and int(wl3.info_d.abs().max().item()) == 0
+    want = env.orc.batched_mll(wl3.forests[:2], wl3.noise[:2], None, wl3.X, wl3.y, wl3.ft, include_scale=False, include_2pi=True)
+    assert np.allclose(eager3[:2].cpu().numpy(), want, rtol=1e-9, atol=1e-8)
 
 
 @pytest.mark.parametrize("N", [300, 301])
