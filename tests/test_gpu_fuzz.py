@@ -1,0 +1,47 @@
+"""Seeded sweep over shapes of the dense MLL / posterior entry point: batch sizes and matrix sizes that land in every
+schedule of Sweep::step — split-K layout with and without look-ahead, filled chunks with a ragged last round split
+over K, chunks smaller than the batch, candidate columns — each checked against the oracle's LU route (the reference's
+arithmetic) on a few forests, and for reproducibility of the same call."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MLL_RTOL, MLL_ATOL = 1e-9, 1e-8
+
+# (N, B, m, C, chunk) — N not a multiple of 128, batch sizes around the schedule thresholds
+CASES = [
+    (1, 1, 3, 0, None), (2, 5, 1, 0, None), (130, 300, 7, 0, None), (257, 64, 50, 0, None), (513, 48, 20, 0, 16),
+    (700, 100, 13, 0, None), (777, 33, 50, 0, None), (900, 12, 50, 0, None), (1100, 64, 50, 0, None),
+    (1300, 40, 30, 0, 24), (1500, 9, 50, 0, None), (2100, 2, 50, 0, None), (2500, 20, 50, 0, None),
+    (640, 16, 50, 90, None), (1000, 70, 25, 130, None), (1400, 3, 50, 300, None),
+]
+
+
+@pytest.mark.parametrize("N,B,m,C,chunk", CASES)
+def test_mll_and_posterior_across_schedules(N, B, m, C, chunk):
+    import bark_amd.fitting as fit
+    from bark_amd import _lib, synthetic as syn
+    from bark_amd.fitting.mll import _run
+    from oracle import oracle as orc
+
+    seed = 1000 * N + B
+    X, y, bounds, ft = syn.mixed_problem(N, seed=seed)
+    F = syn.sample_prior_forests(B, m, bounds, ft, seed=seed + 1)
+    rng = np.random.default_rng(seed)
+    noise, scale = rng.uniform(0.05, 0.3, B), rng.uniform(0.6, 1.5, B)
+    pick = sorted(set([0, B - 1, B // 2]))[:3]
+    if C == 0:
+        got = fit.batched_mll(F, noise, scale, X, y, ft, include_scale=True, include_2pi=True, chunk=chunk)
+        again = fit.batched_mll(F, noise, scale, X, y, ft, include_scale=True, include_2pi=True, chunk=chunk)
+        assert np.array_equal(got, again)  # fixed summation orders: reproducible for a given (B, chunk)
+        want = orc.batched_mll(F[pick], noise[pick], scale[pick], X, y, ft, include_scale=True, include_2pi=True)
+        assert np.allclose(got[pick], want, rtol=MLL_RTOL, atol=MLL_ATOL), (got[pick], want)
+        return
+    cand = syn.mixed_problem(C, seed=seed + 2)[0]
+    mll, mu, var = _run(F, noise, scale, X, y, ft, _lib.MLL_INCLUDE_SCALE, cand=cand, chunk=chunk)
+    mu, var, mll = mu.cpu().numpy(), var.cpu().numpy(), mll.cpu().numpy()
+    mu0, var0 = orc.forest_predict((F[pick], noise[pick], scale[pick]), (X, y), cand, ft)
+    assert np.allclose(mu[pick], mu0, rtol=1e-9, atol=1e-9) and np.allclose(var[pick], var0, rtol=1e-9, atol=1e-9)
+    want = orc.batched_mll(F[pick], noise[pick], scale[pick], X, y, ft, include_scale=True, include_2pi=False)
+    assert np.allclose(mll[pick], want, rtol=MLL_RTOL, atol=MLL_ATOL)
