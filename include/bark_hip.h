@@ -175,10 +175,10 @@ typedef struct {
     float gram_ms;      /* leaf traversal + Gram fill + rhs init, summed over chunks */
     float chol_ms;      /* factorisation sequence (diag + panel + solve, finish, reductions) = total - gram */
     float diag_ms;      /* of which: diag_kernel  (128x128 potrf + inverse + z_j)            */
-    float panel_ms;     /* of which: panel_kernel (fp64 MFMA trailing-panel update, K = 128 j) */
+    float panel_ms;     /* of which: row_kernel / split-K kernels (fp64 MFMA trailing-panel update, K = 128 j) */
     float solve_ms;     /* of which: solve_kernel (MFMA triangular solve by the block inverse) */
     int64_t n_diag_launches, n_panel_launches, n_solve_launches;
-    double panel_flops; /* fp64 flops executed by the panel_kernel launches */
+    double panel_flops; /* fp64 flops executed by the row / split-K launches */
     double solve_flops; /* fp64 flops executed by the solve_kernel launches */
 } bark_mll_timing;
 
