@@ -169,19 +169,20 @@ __device__ __forceinline__ void gemm_kmajor_dma(f64x4 (&acc)[4][4], const double
 // k-tiles kt <= rt.  Wave-row 0 owns row tiles {0,3,4,7}, wave-row 1 owns {1,2,5,6}: 18 (k-tile, row-tile)
 // products each instead of 32, perfectly balanced.
 
-// acc[rt(mt)][nt] += sum_k W[k][r] T[k][c] with W (A operand, row stride 128) upper triangular: k-tiles above
-// a row tile are skipped.  Same LDS-DMA staging/pipeline as gemm_kmajor_dma (K = 128).
-__device__ __forceinline__ void gemm_upper_tri(f64x4 (&acc)[4][4], const int (&rt)[4], const double *__restrict__ W,
+// acc[rt(mt)][nt] += sum_k P[k][r] T[k][c] for the A-operand panel P (row stride 128) = DEF dense 128-row blocks
+// followed by the upper triangular W: in the W block the k-tiles above a row tile are skipped.  T: (DEF + 1) * 128
+// k-rows, row stride ldt.  Same LDS-DMA staging/pipeline as gemm_kmajor_dma.
+template <int DEF>
+__device__ __forceinline__ void gemm_upper_tri(f64x4 (&acc)[4][4], const int (&rt)[4], const double *__restrict__ P,
                                                const double *__restrict__ T, long ldt, double *lds, int tid,
                                                const Lane &q) {
-    constexpr int nk = NB / BK;
+    constexpr int nd = DEF * (NB / BK), nk = nd + NB / BK;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    stage_dma(W, NB, T, ldt, 0, lds, wave, lane);
+    stage_dma(P, NB, T, ldt, 0, lds, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-#pragma unroll
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) stage_dma(W, NB, T, ldt, kt + 1, lds + ((kt + 1) & 1) * STAGE, wave, lane);
+    for (int kt = 0; kt < nd; ++kt) {  // dense block(s): every row tile takes every k-tile
+        stage_dma(P, NB, T, ldt, kt + 1, lds + ((kt + 1) & 1) * STAGE, wave, lane);
         const double *As = lds + (kt & 1) * STAGE;
         const double *Bs = As + BK * LDS_LD;
 #pragma unroll
@@ -190,7 +191,29 @@ __device__ __forceinline__ void gemm_upper_tri(f64x4 (&acc)[4][4], const int (&r
             const double b0 = br[0], b1 = br[16], b2 = br[32], b3 = br[48];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                if (kt <= rt[mt]) {  // wave-uniform
+                const double a = As[(kk * 4 + q.lk) * LDS_LD + rt[mt] * 16 + q.lr];
+                acc[mt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc[mt][1], 0, 0, 0);
+                acc[mt][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b2, acc[mt][2], 0, 0, 0);
+                acc[mt][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b3, acc[mt][3], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#pragma unroll
+    for (int kw = 0; kw < NB / BK; ++kw) {  // k-tile kw of W (nd is even: stage parity == kw & 1)
+        const int kt = nd + kw;
+        if (kt + 1 < nk) stage_dma(P, NB, T, ldt, kt + 1, lds + ((kw + 1) & 1) * STAGE, wave, lane);
+        const double *As = lds + (kw & 1) * STAGE;
+        const double *Bs = As + BK * LDS_LD;
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            const double *br = Bs + (kk * 4 + q.lk) * LDS_LD + q.wc * 64 + q.lr;
+            const double b0 = br[0], b1 = br[16], b2 = br[32], b3 = br[48];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                if (kw <= rt[mt]) {  // wave-uniform
                     const double a = As[(kk * 4 + q.lk) * LDS_LD + rt[mt] * 16 + q.lr];
                     acc[mt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc[mt][0], 0, 0, 0);
                     acc[mt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc[mt][1], 0, 0, 0);
@@ -229,7 +252,8 @@ inline unsigned xcd_grid(int ntiles, int Bc) {
 struct Mats {
     double *A;            // (Bc, Npad, ld)
     long ld, bstride;
-    double *W;            // (Bc, 128, 128)  inverse of the current diagonal factor
+    double *W;            // (Bc, 256, 128)  rows 128..255: W_j = inverse of the current diagonal factor; rows 0..127:
+                          //                 -U[j-1,j] W_j (gw_kernel; pipelined schedule only)
     double *yz;           // (Bc, Npad)      y on entry, z = U^-T y on exit
     double *accum;        // (Bc, 2)         quad, logdet
     int32_t *info;        // (Bc,)
@@ -244,6 +268,9 @@ struct Mats {
     const double *noise;    // (Bc,)
     int nW, m, N;  // dwords of leaf ids per point, trees, real points
 };
+
+constexpr size_t W_STRIDE = (size_t)2 * NB * NB;  // doubles per matrix in Mats::W
+__device__ __forceinline__ double *w_block(const Mats &p, int b) { return p.W + (size_t)b * W_STRIDE + (size_t)NB * NB; }
 
 // ---------------------------------------------------------------------------------------------
 // diag_kernel: factor + invert the j-th diagonal block (128x128) of every matrix of the chunk.
@@ -457,8 +484,8 @@ struct UpperBlocks<3> {
 constexpr int UPD_STAGE = BK * LDS_LD;  // one operand: 16 rows x (128 + 16) doubles
 
 template <int W>
-__device__ __forceinline__ void diag_update(const double *__restrict__ tile, long ld, const double *__restrict__ panel,
-                                            bool has_panel, double *lds, double *S, int lane, int lr, int lk) {
+__device__ __forceinline__ void diag_update(const double *__restrict__ tile, long ld, const double *__restrict__ panel0,
+                                            int nkb, double *lds, double *S, int lane, int lr, int lk) {
     using T = UpperBlocks<W>;
     double pre[9][4];
 #pragma unroll
@@ -468,7 +495,7 @@ __device__ __forceinline__ void diag_update(const double *__restrict__ tile, lon
     f64x4 acc[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
-    if (has_panel) {  // workgroup-uniform: every wave takes the same barriers
+    auto apply = [&](const double *panel) {  // acc += panel' panel (128 k-rows) on this wave's sub-blocks
         auto stage = [&](int kt, double *st) {  // wave W moves rows W, W+4, W+8, W+12 of the k-tile
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp)
@@ -494,7 +521,11 @@ __device__ __forceinline__ void diag_update(const double *__restrict__ tile, lon
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-    }
+    };
+    // workgroup-uniform branches: every wave takes the same barriers.  The plain schedule (nkb == 1) runs the second
+    // call only, whose code is the critical path of small batches.
+    if (nkb > 1) apply(panel0);
+    if (nkb > 0) apply(panel0 + (size_t)(nkb - 1) * NB * ld);
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         double *blk = S + blk_off(T::rb[i], T::cb[i]);
@@ -503,7 +534,9 @@ __device__ __forceinline__ void diag_update(const double *__restrict__ tile, lon
     }
 }
 
-__global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j) {
+// nkb: trailing block rows of U still to be applied to the stored diagonal tile, D = P - sum_{j-nkb <= k < j} U[k,j]'U[k,j]
+// (1 in the plain schedule, 2 in the pipelined one, 0 for j == 0).
+__global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, b = blockIdx.x;
     const Lane q = lane_of(tid);
@@ -522,18 +555,18 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j) {
     double *vec = lds + NBLK * SB * SB + 4 * SB * TS;         // [2][128] y | upper-half partial sums
     double *red = vec + 2 * NB;                               // [8]
     {
-        // D = P - U[j-1,j]'U[j-1,j] on the upper block triangle (the product stages alias S: the update's last barrier
+        // D = P - sum_k U[k,j]'U[k,j] on the upper block triangle (the product stages alias S: the update's last barrier
         // precedes the writes of S)
-        const double *prev = Ab + (size_t)(j > 0 ? j - 1 : 0) * NB * p.ld + (size_t)j * NB;  // U[j-1, j]
+        const double *prev = Ab + (size_t)(j - nkb) * NB * p.ld + (size_t)j * NB;  // U[j-nkb, j]
         const int wsel = __builtin_amdgcn_readfirstlane(wave);
         if (wsel == 0)
-            diag_update<0>(tile, p.ld, prev, j > 0, lds, S, lane, q.lr, q.lk);
+            diag_update<0>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk);
         else if (wsel == 1)
-            diag_update<1>(tile, p.ld, prev, j > 0, lds, S, lane, q.lr, q.lk);
+            diag_update<1>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk);
         else if (wsel == 2)
-            diag_update<2>(tile, p.ld, prev, j > 0, lds, S, lane, q.lr, q.lk);
+            diag_update<2>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk);
         else
-            diag_update<3>(tile, p.ld, prev, j > 0, lds, S, lane, q.lr, q.lk);
+            diag_update<3>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk);
     }
     __syncthreads();
 
@@ -637,7 +670,7 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j) {
 
     // --- W_j out, sub-block by sub-block (explicit zeros below the block diagonal: solve_kernel multiplies the full
     // tile; the diagonal sub-blocks are upper triangular with exact zeros already) --------------------------------
-    double *Wb = p.W + (size_t)b * NB * NB;
+    double *Wb = w_block(p, b);
     {
         const int r = tid >> 4, c = tid & 15;  // one element of every 16 x 16 sub-block per thread
 #pragma unroll
@@ -792,8 +825,10 @@ __device__ __forceinline__ void y_commit(const double *part, double *yi, int tid
 // Fusing the triangular solve into this kernel's epilogue was built twice this round (T kept in registers; T read
 // back through L2 by the same workgroup) and rejected on measurements: DESIGN.md, "Fused solve".
 // ---------------------------------------------------------------------------------------------
+// kdone: block rows of the K range this launch covers (j in the plain schedule; j - 1 in the pipelined one, where
+// solve_kernel<1> / diag_kernel apply the rest).
 template <int GEN>  // 0: A tile read from HBM; 1 + LeafRep: A generated from the leaf codes (bytes8 / bytes7 / bits)
-__global__ __launch_bounds__(THREADS, 2) void row_kernel(Mats p, int j, int n_right, int n_tiles) {
+__global__ __launch_bounds__(THREADS, 2) void row_kernel(Mats p, int j, int kdone, int n_right, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
     int b, t;
@@ -804,7 +839,7 @@ __global__ __launch_bounds__(THREADS, 2) void row_kernel(Mats p, int j, int n_ri
     const int cb = t < n_right ? j + 1 + t : j + 1;
     f64x4 acc[4][4];
     zero_acc(acc);
-    gemm_kmajor_dma(acc, Ab + (size_t)rb * NB, p.ld, Ab + (size_t)cb * NB, p.ld, j * NB, lds, tid, q);
+    gemm_kmajor_dma(acc, Ab + (size_t)rb * NB, p.ld, Ab + (size_t)cb * NB, p.ld, kdone * NB, lds, tid, q);
     form_tile<GEN>(acc, p, b, rb, cb, Ab + (size_t)rb * NB * p.ld + (size_t)cb * NB, lds, tid, q);
 }
 
@@ -902,8 +937,55 @@ __global__ __launch_bounds__(THREADS) void panel_reduce_kernel(Mats p, int j, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// solve_kernel: U[j,i] = W_j' T[j,i] for every tile right of the diagonal; y_i -= U[j,i]' z_j.
+// gw_kernel (pipelined schedule): rows 0..127 of Mats::W := -G_j, G_j = U[j-1,j] W_j (128 x 128; W_j upper triangular,
+// so column r only sums k' <= r).  Grid (4, Bc): workgroup g owns the rows k in [32 g, 32 g + 32) of G, wave w the
+// columns [32 w, 32 w + 32).  The 32 x 128 slice of U[j-1,j] goes through LDS (row stride 130: the A-fragment read,
+// 16 rows x 4 columns per wave, is conflict-free per half wave); W_j is read from L2 in the B-fragment pattern.
 // ---------------------------------------------------------------------------------------------
+constexpr int GW_ROWS = 32, GW_LD = NB + 2;
+__global__ __launch_bounds__(THREADS) void gw_kernel(Mats p, int j) {
+    __shared__ double Us[GW_ROWS * GW_LD];
+    const int tid = threadIdx.x, g = blockIdx.x, b = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const double *Ub = p.A + (size_t)b * p.bstride + ((size_t)(j - 1) * NB + g * GW_ROWS) * p.ld + (size_t)j * NB;
+    {
+        const int r = tid >> 3, c0 = (tid & 7) * 16;  // 16 consecutive doubles of one row per thread
+        const f64x2 *src = reinterpret_cast<const f64x2 *>(Ub + (size_t)r * p.ld + c0);
+        f64x2 *dst = reinterpret_cast<f64x2 *>(Us + r * GW_LD + c0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[i] = src[i];
+    }
+    __syncthreads();
+    const double *Wj = w_block(p, b);
+    double *out = p.W + (size_t)b * W_STRIDE + (size_t)g * GW_ROWS * NB;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int c0 = wave * 32 + ct * 16;
+        f64x4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
+        const int nkk = (c0 + 16) / 4;  // k' < c0 + 16: below that row W_j's columns c0.. are zero
+#pragma unroll 8
+        for (int kk = 0; kk < nkk; ++kk) {
+            const double w = Wj[(size_t)(kk * 4 + lk) * NB + c0 + lr];
+            const double u0 = Us[lr * GW_LD + kk * 4 + lk], u1 = Us[(16 + lr) * GW_LD + kk * 4 + lk];
+            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, w, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(u1, w, a1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            out[(size_t)(lk + 4 * v) * NB + c0 + lr] = -a0[v];
+            out[(size_t)(16 + lk + 4 * v) * NB + c0 + lr] = -a1[v];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// solve_kernel: U[j,i] = W_j' T[j,i] for every tile right of the diagonal; y_i -= U[j,i]' z_j.
+// DEF == 1 (pipelined schedule): the stored tile lacks the last block row of its sum, T = T' - U[j-1,j]'U[j-1,i], and
+//   U[j,i] = W_j' T' - (U[j-1,j] W_j)' U[j-1,i] = [-G_j ; W_j]' [U[j-1,i] ; T'[j,i]]
+// is ONE K = 256 product: the right operand is the contiguous 256-row panel of column block i starting at block row
+// j-1, the left one the stacked (256 x 128) block Mats::W that gw_kernel and diag_kernel fill.
+// ---------------------------------------------------------------------------------------------
+template <int DEF>
 __global__ __launch_bounds__(THREADS, 2) void solve_kernel(Mats p, int j, int n_right) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
@@ -913,7 +995,7 @@ __global__ __launch_bounds__(THREADS, 2) void solve_kernel(Mats p, int j, int n_
     const int cb = j + 1 + t;
     double *Ab = p.A + (size_t)b * p.bstride;
     double *tile = Ab + (size_t)j * NB * p.ld + (size_t)cb * NB;
-    const double *Wb = p.W + (size_t)b * NB * NB;
+    const double *Pb = p.W + (size_t)b * W_STRIDE + (size_t)(1 - DEF) * NB * NB;
 
     f64x4 acc[4][4];
     zero_acc(acc);
@@ -921,7 +1003,7 @@ __global__ __launch_bounds__(THREADS, 2) void solve_kernel(Mats p, int j, int n_
     // (readfirstlane: the skip branches around MFMAs must be scalar branches, MFMA ignores EXEC)
     const int wr_u = __builtin_amdgcn_readfirstlane(q.wr);
     const int rt[4] = {wr_u ? 1 : 0, wr_u ? 2 : 3, wr_u ? 5 : 4, wr_u ? 6 : 7};
-    gemm_upper_tri(acc, rt, Wb, tile, p.ld, lds, tid, q);
+    gemm_upper_tri<DEF>(acc, rt, Pb, tile - (size_t)DEF * NB * p.ld, p.ld, lds, tid, q);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -1137,6 +1219,12 @@ constexpr long TAIL_MAX_WGS = BARK_TAIL_MAX_WGS;  // ragged_tail: largest last r
 // under-filled steps can split K (build-time tuning constant; measured at N = 4096: B = 8 9.97 -> 5.62 ms, B = 16
 // 11.6 -> 9.4 ms, B = 32 16.9 -> 16.3 ms, no gain from B = 64 on)
 constexpr int SPLITK_LAYOUT_MAX_TILES = BARK_SPLITK_LAYOUT_MAX_TILES;
+#ifndef BARK_PIPE_STREAMS
+#define BARK_PIPE_STREAMS 2
+#endif
+#ifndef BARK_PIPELINE
+#define BARK_PIPELINE 1  // chunks outside the split-K layout use Sweep::step_pipelined (0: the plain schedule, for A/B runs)
+#endif
 
 struct Layout {
     int64_t npad, cpad, ncols, ld, W;
@@ -1157,7 +1245,7 @@ Layout make_layout(int64_t N, int64_t C, int64_t m, int64_t Bc) {
     L.off_A = o;
     o = align256(o + (size_t)Bc * L.npad * L.ld * sizeof(double));
     L.off_W = o;
-    o = align256(o + (size_t)Bc * NB * NB * sizeof(double));
+    o = align256(o + (size_t)Bc * W_STRIDE * sizeof(double));
     L.off_yz = o;
     o = align256(o + (size_t)Bc * L.npad * sizeof(double));
     L.off_acc = o;
@@ -1214,7 +1302,8 @@ int set_lds_limits() {
         if (e == hipSuccess) e = set(reinterpret_cast<const void *>(row_kernel<3>), GEMM_LDS);
         if (e == hipSuccess) e = set(reinterpret_cast<const void *>(panel_split_kernel), GEMM_LDS);
         if (e == hipSuccess) e = set(reinterpret_cast<const void *>(vtv_kernel), GEMM_LDS);
-        if (e == hipSuccess) e = set(reinterpret_cast<const void *>(solve_kernel), GEMM_LDS);
+        if (e == hipSuccess) e = set(reinterpret_cast<const void *>(solve_kernel<0>), GEMM_LDS);
+        if (e == hipSuccess) e = set(reinterpret_cast<const void *>(solve_kernel<1>), GEMM_LDS);
         status[dev] = (int)e;
     });
     if (status[dev] != 0)
@@ -1237,7 +1326,7 @@ struct Sweep {
     int nrb_steps = 0;                            // block columns that get a step() (== nrb)
     bark_ctx *res = nullptr;
     int nrb = 0, ncb = 0;
-    bool fused = false, splitk = false;
+    bool fused = false, splitk = false, pipelined = false;
     int rep = 0;
     double *slabs = nullptr;
     // timing mode only: one event pair per launch, recorded on the stream of the launch
@@ -1255,26 +1344,27 @@ struct Sweep {
         return BARK_OK;
     }
 
-    int launch_rows(hipStream_t st, int j, int n_right, int n_tiles) {
+    int launch_rows(hipStream_t st, int j, int kdone, int n_right, int n_tiles) {
         const dim3 g(xcd_grid(n_tiles, p.Bc)), blk(THREADS);
         if (!fused)
-            hipLaunchKernelGGL(row_kernel<0>, g, blk, GEMM_LDS, st, p, j, n_right, n_tiles);
+            hipLaunchKernelGGL(row_kernel<0>, g, blk, GEMM_LDS, st, p, j, kdone, n_right, n_tiles);
         else if (rep == REP_BITS)
-            hipLaunchKernelGGL(row_kernel<1 + REP_BITS>, g, blk, GEMM_LDS, st, p, j, n_right, n_tiles);
+            hipLaunchKernelGGL(row_kernel<1 + REP_BITS>, g, blk, GEMM_LDS, st, p, j, kdone, n_right, n_tiles);
         else if (rep == REP_BYTES7)
-            hipLaunchKernelGGL(row_kernel<1 + REP_BYTES7>, g, blk, GEMM_LDS, st, p, j, n_right, n_tiles);
+            hipLaunchKernelGGL(row_kernel<1 + REP_BYTES7>, g, blk, GEMM_LDS, st, p, j, kdone, n_right, n_tiles);
         else
-            hipLaunchKernelGGL(row_kernel<1 + REP_BYTES8>, g, blk, GEMM_LDS, st, p, j, n_right, n_tiles);
+            hipLaunchKernelGGL(row_kernel<1 + REP_BYTES8>, g, blk, GEMM_LDS, st, p, j, kdone, n_right, n_tiles);
         BARK_LAUNCH_CHECK();
+        panel_flops += 2.0 * NB * NB * (double)(kdone * NB) * (double)n_tiles * (double)p.Bc;
         return BARK_OK;
     }
 
-    int launch_diag(int j) {
+    int launch_diag(int j, int nkb) {
         int r;
         if (timed) diag_marks.push_back(ev.size());
         if ((r = mark_on(main))) return r;
         hipLaunchKernelGGL(diag_kernel, dim3((unsigned)p.Bc), dim3(THREADS), p.Bc <= DIAG_EXCLUSIVE_MAX_BC ? DIAG_LDS_EXCLUSIVE : DIAG_LDS,
-                           main, p, j);
+                           main, p, j, nkb);
         BARK_LAUNCH_CHECK();
         return mark_on(main);
     }
@@ -1373,6 +1463,7 @@ struct Sweep {
     // bulk (S slabs) is launched on a third stream right after solve(j-2) and runs beside the whole of step j-1; on
     // the critical path of step j remain diag(j) || the rank-128 slab of block row j-1, the reduce and the solve.
     int step(int j) {
+        if (pipelined) return step_pipelined(j);
         hipStream_t s = main, ps = panel;
         const int bc = p.Bc;
         const int n_right = ncb - j - 1;
@@ -1384,7 +1475,7 @@ struct Sweep {
         // j == 0: with a materialised A the tiles T = A are in place; in fused-Gram sweeps the K = 0 launch writes them
         const bool has_rows = (j >= 1 || fused) && n_tiles > 0;
         if (has_rows && (r = fork(6 * j))) return r;  // rows(j) wait for everything enqueued so far (solve(j-1))
-        if ((r = launch_diag(j))) return r;
+        if ((r = launch_diag(j, j > 0 ? 1 : 0))) return r;
         if (has_rows) {
             if (timed) panel_marks.push_back(ev.size());
             if ((r = mark_on(ps))) return r;
@@ -1399,8 +1490,7 @@ struct Sweep {
                 int tail, St;
                 ragged_tail(j, n_tiles, tail, St);
                 if (tail > 0) {
-                    if ((r = launch_rows(ps, j, n_right, tail))) return r;
-                    panel_flops += 2.0 * NB * NB * (double)(j * NB) * (double)tail * (double)bc;
+                    if ((r = launch_rows(ps, j, j, n_right, tail))) return r;
                 }
                 if (tail < n_tiles) {
                     if ((r = launch_split(ps, j, 0, j, St, 0, St, tail, n_tiles - tail))) return r;
@@ -1413,7 +1503,7 @@ struct Sweep {
         if (n_right > 0) {
             if (timed) solve_marks.push_back(ev.size());
             if ((r = mark_on(s))) return r;
-            hipLaunchKernelGGL(solve_kernel, dim3(xcd_grid(n_right, bc)), dim3(THREADS), GEMM_LDS, s, p, j, n_right);
+            hipLaunchKernelGGL(solve_kernel<0>, dim3(xcd_grid(n_right, bc)), dim3(THREADS), GEMM_LDS, s, p, j, n_right);
             BARK_LAUNCH_CHECK();
             if ((r = mark_on(s))) return r;
             // 18 of the 32 (k-tile, row-tile) products per wave are executed (zero k-tiles of W_j skipped)
@@ -1427,6 +1517,61 @@ struct Sweep {
             BARK_HIP_CHECK(hipEventRecord(res->events[6 * j2 + 2], la_stream));
         }
         return BARK_OK;
+    }
+
+    // ---- pipelined schedule (chunks with enough matrices to fill the chip, i.e. not in the split-K layout) -----------
+    // The row launch of block row j covers only the block rows k < j-1 of its K range ("bulk"), which are final once
+    // solve(j-2) has retired; the last block row is applied by the consumers — solve_kernel<1>(j) (one K = 256 product,
+    // see there) and diag_kernel(j+1) (two block rows instead of one).  So bulk(j+2) runs beside diag(j+1), gw(j+1)
+    // and the HBM-bound solve(j+1) instead of waiting for them, and — alternating between the two helper streams —
+    // beside the ragged last round of bulk(j+1):
+    //   caller's stream  diag(j) -> gw(j) -> [wait bulk(j)] solve(j) -> diag(j+1) -> ...
+    //   helper streams   bulk(j+2) after solve(j)
+    // Every bulk launch is awaited on the caller's stream at its own step, so the pattern stays fork/join (capturable).
+    int kdone(int j) const { return j > 0 ? j - 1 : 0; }
+    int tiles_of(int j) const { return (ncb - j - 1) + ((j + 1 < nrb) ? 1 : 0); }
+    // a K = 0 launch only generates A (fused sweeps); with a materialised A there is nothing to do
+    bool has_bulk(int j) const { return j < nrb_steps && tiles_of(j) > 0 && (kdone(j) > 0 || fused); }
+    int launch_bulk(int j) {  // everything enqueued on `main` so far precedes it
+        if (!has_bulk(j)) return BARK_OK;
+        hipStream_t st = (BARK_PIPE_STREAMS > 1 && (j & 1)) ? la_stream : panel;
+        int r;
+        BARK_HIP_CHECK(hipEventRecord(res->events[6 * j + 3], main));
+        BARK_HIP_CHECK(hipStreamWaitEvent(st, res->events[6 * j + 3], 0));
+        if (timed) panel_marks.push_back(ev.size());
+        if ((r = mark_on(st))) return r;
+        if ((r = launch_rows(st, j, kdone(j), ncb - j - 1, tiles_of(j)))) return r;
+        if ((r = mark_on(st))) return r;
+        BARK_HIP_CHECK(hipEventRecord(res->events[6 * j + 2], st));
+        return BARK_OK;
+    }
+    int step_pipelined(int j) {
+        const int bc = p.Bc, n_right = ncb - j - 1;
+        int r;
+        if (j == 0) {
+            if ((r = launch_bulk(0))) return r;
+            if ((r = launch_bulk(1))) return r;
+        }
+        // the stored P_jj comes from the row launch of block row j-1: block rows kdone(j-1) .. j-1 are still to apply
+        if ((r = launch_diag(j, j > 0 ? j - kdone(j - 1) : 0))) return r;
+        const bool deferred = j > kdone(j);
+        if (deferred && n_right > 0) {
+            hipLaunchKernelGGL(gw_kernel, dim3(NB / GW_ROWS, (unsigned)bc), dim3(THREADS), 0, main, p, j);
+            BARK_LAUNCH_CHECK();
+        }
+        if (has_bulk(j)) BARK_HIP_CHECK(hipStreamWaitEvent(main, res->events[6 * j + 2], 0));
+        if (n_right > 0) {
+            if (timed) solve_marks.push_back(ev.size());
+            if ((r = mark_on(main))) return r;
+            if (deferred)
+                hipLaunchKernelGGL(solve_kernel<1>, dim3(xcd_grid(n_right, bc)), dim3(THREADS), GEMM_LDS, main, p, j, n_right);
+            else
+                hipLaunchKernelGGL(solve_kernel<0>, dim3(xcd_grid(n_right, bc)), dim3(THREADS), GEMM_LDS, main, p, j, n_right);
+            BARK_LAUNCH_CHECK();
+            if ((r = mark_on(main))) return r;
+            solve_flops += ((deferred ? 32.0 : 0.0) + 18.0) / 32.0 * 2.0 * NB * NB * (double)NB * (double)n_right * (double)bc;
+        }
+        return launch_bulk(j + 2);
     }
 
     // fill *t from the recorded events (synchronises); [t_begin, t_end] bracket the whole call on `caller`
@@ -1526,6 +1671,11 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
     sw.ncb = ncb;
     sw.fused = fused;
     sw.splitk = splitk;
+    // Pipelined schedule: pays whenever the plain schedule leaves ragged rounds of workgroups (measured at N = 4096:
+    // B = 40 +15 %, 64 +7 %, 96 +9 %, 160 +5 %, 192 +4 %; N = 8192, B = 32 +7 %; N = 2048, B = 128..192 +5 %), but not
+    // when Bc is a multiple of the 256 CUs — every round is then full or exactly half full, and the K = 256 solve and
+    // gw_kernel only cost (B = 256: -1.5 % at N = 4096, -2 % at N = 1024..2048) — nor for fewer than 8 block rows.
+    const bool pipeline_ok = BARK_PIPELINE != 0 && !splitk && nrb >= 8;  // decided per chunk below
     sw.rep = rep;
     sw.slabs = slabs;
     sw.timed = timing != nullptr;
@@ -1612,6 +1762,7 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
     if ((rc = sw.mark_on(caller))) return rc;
     for (int64_t c0 = 0; c0 < B; c0 += Bc) {  // chunks of Bc resident matrices, one after the other
         const int64_t bc = (B - c0 < Bc) ? (B - c0) : Bc;
+        sw.pipelined = pipeline_ok && (bc % 256) != 0;
         if ((rc = prologue(c0, bc))) return rc;
         for (int j = 0; j < nrb; ++j)
             if ((rc = sw.step(j))) return rc;

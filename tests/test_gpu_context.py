@@ -294,3 +294,24 @@ def test_product_path_launches_no_torch_compute_kernels(env):
     assert any("bark" in n for n in names), names
     foreign = [n for n in names if "at::native" in n or "rocblas" in n.lower() or "Cijk" in n]
     assert not foreign, foreign
+
+
+def test_pipelined_schedule_is_hipgraph_capturable(env):
+    """Sweep::step_pipelined forks the bulk row launches onto both helper streams two steps ahead; every one of them is
+    awaited on the caller's stream at its own step, so the call is still a capturable fork/join."""
+    import bench
+
+    torch = env.torch
+    wl = bench.Workload(1200, 8, 50, 130, seed_base=1200, rank_offset=0)  # 10 block rows x 130 matrices: pipelined
+    wl.run()
+    torch.cuda.synchronize()
+    eager = wl.mll_d.clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        wl.stream = env.lib.stream_ptr()
+        wl.run()
+    wl.mll_d.zero_()
+    g.replay()
+    g.replay()
+    torch.cuda.synchronize()
+    assert bool((wl.mll_d == eager).all()) and int(wl.info_d.abs().max().item()) == 0

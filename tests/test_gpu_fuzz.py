@@ -1,6 +1,6 @@
 """Seeded sweep over shapes of the dense MLL / posterior entry point: batch sizes and matrix sizes that land in every
-schedule of Sweep::step — split-K layout with and without look-ahead, filled chunks with a ragged last round split
-over K, chunks smaller than the batch, candidate columns — each checked against the oracle's LU route (the reference's
+schedule of Sweep::step — split-K layout with and without look-ahead, filled chunks in the plain (ragged last round
+split over K) and the pipelined schedule, chunks smaller than the batch, candidate columns — each checked against the oracle's LU route (the reference's
 arithmetic) on a few forests, and for reproducibility of the same call."""
 import numpy as np
 import pytest
@@ -15,6 +15,10 @@ CASES = [
     (700, 100, 13, 0, None), (777, 33, 50, 0, None), (900, 12, 50, 0, None), (1100, 64, 50, 0, None),
     (1300, 40, 30, 0, 24), (1500, 9, 50, 0, None), (2100, 2, 50, 0, None), (2500, 20, 50, 0, None),
     (640, 16, 50, 90, None), (1000, 70, 25, 130, None), (1400, 3, 50, 300, None),
+    # filled chunks of >= 8 block rows whose size is not a multiple of 256: the pipelined schedule (Sweep::step_pipelined),
+    # generated and materialised Gram, candidate columns, a shorter last chunk, and its plain-schedule neighbour B = 256
+    (1100, 130, 50, 0, None), (1300, 200, 20, 0, 120), (2100, 70, 50, 0, None), (1000, 150, 25, 130, None),
+    (1500, 100, 30, 200, None), (1100, 256, 50, 0, None),
 ]
 
 
