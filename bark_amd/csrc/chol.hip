@@ -860,12 +860,14 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(Mats p, int j, 
     const Lane q = lane_of(tid);
     const int tl = ts / S, s = ts - tl * S, t = t_off + tl;
     const int rb = t < n_right ? j : j + 1, cb = t < n_right ? j + 1 + t : j + 1;
-    const int nkb = kb_hi - kb_lo;
-    const int kb0 = kb_lo + (int)(((long)nkb * s) / S), kb1 = kb_lo + (int)(((long)nkb * (s + 1)) / S);  // block rows [kb0, kb1)
-    const double *Ab = p.A + (size_t)b * p.bstride + (size_t)kb0 * NB * p.ld;
+    // slab s = k-tiles (16 rows) [k0, k1) of the range: cut at k-tile, not block-row, granularity, so the S workgroups of
+    // a tile differ by one k-tile at most (with 7.45 block rows per slab the 8-row slabs set the pace: 7 % idle)
+    const long nkt = (long)(kb_hi - kb_lo) * (NB / BK);
+    const int k0 = kb_lo * (NB / BK) + (int)((nkt * s) / S), k1 = kb_lo * (NB / BK) + (int)((nkt * (s + 1)) / S);
+    const double *Ab = p.A + (size_t)b * p.bstride + (size_t)k0 * BK * p.ld;
     f64x4 acc[4][4];
     zero_acc(acc);
-    gemm_kmajor_dma(acc, Ab + (size_t)rb * NB, p.ld, Ab + (size_t)cb * NB, p.ld, (kb1 - kb0) * NB, lds, tid, q);
+    gemm_kmajor_dma(acc, Ab + (size_t)rb * NB, p.ld, Ab + (size_t)cb * NB, p.ld, (k1 - k0) * BK, lds, tid, q);
     double *slab = slabs + ((size_t)((size_t)b * n_tiles + tl) * S_tot + s_off + s) * NB * NB;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -1195,15 +1197,31 @@ __global__ __launch_bounds__(THREADS) void quadform_kernel(const double *__restr
 }
 
 constexpr int SPLITK_SLOTS = 512;  // workgroup slots split-K aims to fill (2 per CU)
-constexpr int SPLITK_MAX = 16;
-constexpr size_t SLAB_SET_TILES = SPLITK_SLOTS + SPLITK_SLOTS / 2;  // slabs (128 x 128) of one set
-#ifndef BARK_LA_SLOTS
-#define BARK_LA_SLOTS 512
+#ifndef BARK_SPLITK_MAX
+#define BARK_SPLITK_MAX 32
 #endif
-// Workgroup slots the look-ahead bulk of a split-K step aims to fill.  (Leaving an eighth of the slots free for the
-// previous step's small critical-path kernels was tried: no gain for one N = 16384 matrix, and the coarser integer
-// split factor cost 12 % with 10^4 candidate columns: 82.5 vs 73.0 ms.)
-constexpr int LA_SLOTS = BARK_LA_SLOTS;
+constexpr int SPLITK_MAX = BARK_SPLITK_MAX;
+#ifndef BARK_LA_SLOTS
+#define BARK_LA_SLOTS 448
+#endif
+#ifndef BARK_LA_SLOTS_CHAIN
+#define BARK_LA_SLOTS_CHAIN 384
+#endif
+#ifndef BARK_LA_BULK_WORK
+#define BARK_LA_BULK_WORK 2400
+#endif
+// Workgroups the look-ahead bulk of a split-K step aims at (nearest integer split factor, never more than
+// SPLITK_SLOTS).  The bulk runs beside the previous step's critical-path kernels, and resident workgroups are never
+// pre-empted: a bulk that fills every slot for its ~250 us starves them (solve_kernel 20 -> 200 us in the kernel
+// timeline of one N = 16384 matrix) and delays its own successor.  So an eighth of the slots stays free — and a quarter
+// in steps whose bulk is shorter than the critical path anyway ((tiles x matrices) x block rows < LA_BULK_WORK, ~150 us
+// of MFMA work).  Measured (448 | 384 vs 512 everywhere): N = 16384 lone 30.2 -> 28.7 ms, N = 8192 x 2 10.7 -> 9.4,
+// N = 4096 x 8 5.59 -> 5.2.
+constexpr int LA_SLOTS = BARK_LA_SLOTS, LA_SLOTS_CHAIN = BARK_LA_SLOTS_CHAIN;
+constexpr long LA_BULK_WORK = BARK_LA_BULK_WORK;
+// slabs (128 x 128) of one set: a split step has fewer than SPLITK_SLOTS / 2 tiles x matrices, each with S slabs
+// (tiles x matrices x S <= the slots aimed at) plus one for the last block row
+constexpr size_t SLAB_SET_TILES = (LA_SLOTS > SPLITK_SLOTS ? LA_SLOTS : SPLITK_SLOTS) + SPLITK_SLOTS / 2;
 #ifndef BARK_LA_MIN_WORK
 #define BARK_LA_MIN_WORK 600
 #endif
@@ -1219,6 +1237,9 @@ constexpr long TAIL_MAX_WGS = BARK_TAIL_MAX_WGS;  // ragged_tail: largest last r
 // under-filled steps can split K (build-time tuning constant; measured at N = 4096: B = 8 9.97 -> 5.62 ms, B = 16
 // 11.6 -> 9.4 ms, B = 32 16.9 -> 16.3 ms, no gain from B = 64 on)
 constexpr int SPLITK_LAYOUT_MAX_TILES = BARK_SPLITK_LAYOUT_MAX_TILES;
+#ifndef BARK_LA_STREAMS
+#define BARK_LA_STREAMS 2
+#endif
 #ifndef BARK_PIPE_STREAMS
 #define BARK_PIPE_STREAMS 2
 #endif
@@ -1323,6 +1344,7 @@ struct Sweep {
     Mats p;
     hipStream_t main = nullptr, panel = nullptr;  // panel == main: no overlap
     hipStream_t la_stream = nullptr;              // look-ahead launches of the split-K bulk (null: no look-ahead)
+    hipStream_t la_stream2 = nullptr;             // ... of the odd steps (consecutive bulks do not queue behind each other)
     int nrb_steps = 0;                            // block columns that get a step() (== nrb)
     bark_ctx *res = nullptr;
     int nrb = 0, ncb = 0;
@@ -1389,6 +1411,10 @@ struct Sweep {
         const int n_tiles = (ncb - j - 1) + ((j + 1 < nrb) ? 1 : 0);
         if (!splitk || j < 1 || n_tiles <= 0 || n_tiles * p.Bc >= SPLITK_SLOTS / 2 || nkb < 1) return 1;
         int S = slots / (n_tiles * p.Bc);
+        if (slots != SPLITK_SLOTS) {  // look-ahead bulk: aim at `slots` workgroups (nearest S), never more than SPLITK_SLOTS
+            S = (2 * slots + n_tiles * p.Bc) / (2 * n_tiles * p.Bc);
+            while (S > 1 && S * n_tiles * p.Bc > SPLITK_SLOTS) --S;
+        }
         if (S < 1) S = 1;
         if (S > nkb) S = nkb;
         if (S > SPLITK_MAX) S = SPLITK_MAX;
@@ -1402,6 +1428,10 @@ struct Sweep {
         if (la_stream == nullptr || j < 2 || j >= nrb_steps || split_factor(j, j) <= 1) return false;
         const long n_tiles = (ncb - j - 1) + ((j + 1 < nrb) ? 1 : 0);
         return n_tiles * p.Bc * (long)(j - 1) >= LA_MIN_WORK;
+    }
+    int la_slots(int j) const {  // look-ahead step j: workgroups its bulk (block rows [0, j-1)) aims at
+        const long n_tiles = (ncb - j - 1) + ((j + 1 < nrb) ? 1 : 0);
+        return n_tiles * p.Bc * (long)(j - 1) >= LA_BULK_WORK ? LA_SLOTS : LA_SLOTS_CHAIN;
     }
     double *slab_set(int j) const { return slabs + (size_t)(j & 1) * SLAB_SET_TILES * NB * NB; }
 
@@ -1471,7 +1501,7 @@ struct Sweep {
         const int n_tiles = n_right + n_diag;
         int r;
         const bool la = lookahead(j);
-        const int S = la ? split_factor(j, j - 1, LA_SLOTS) : split_factor(j, j);
+        const int S = la ? split_factor(j, j - 1, la_slots(j)) : split_factor(j, j);
         // j == 0: with a materialised A the tiles T = A are in place; in fused-Gram sweeps the K = 0 launch writes them
         const bool has_rows = (j >= 1 || fused) && n_tiles > 0;
         if (has_rows && (r = fork(6 * j))) return r;  // rows(j) wait for everything enqueued so far (solve(j-1))
@@ -1510,11 +1540,16 @@ struct Sweep {
             solve_flops += (18.0 / 32.0) * 2.0 * NB * NB * (double)NB * (double)n_right * (double)bc;
         }
         if (lookahead(j + 2)) {  // rows <= j are final: the bulk of step j+2 can start now
-            const int j2 = j + 2, S2 = split_factor(j2, j2 - 1, LA_SLOTS);
+            const int j2 = j + 2, S2 = split_factor(j2, j2 - 1, la_slots(j2));
             BARK_HIP_CHECK(hipEventRecord(res->events[6 * j + 3], s));
-            BARK_HIP_CHECK(hipStreamWaitEvent(la_stream, res->events[6 * j + 3], 0));
-            if ((r = launch_split(la_stream, j2, 0, j2 - 1, S2, 0, S2 + 1))) return r;
-            BARK_HIP_CHECK(hipEventRecord(res->events[6 * j2 + 2], la_stream));
+            // bulk-bound steps alternate between two streams, so that a bulk does not queue behind the last workgroups
+            // of its predecessor (one N = 16384 matrix 28.7 -> 28.1 ms, with 10^4 candidates 73.5 -> 69.3); in
+            // critical-path-bound steps two resident bulks would only take slots from the critical path
+            // (N = 4096, B = 8: 5.04 -> 5.26 ms)
+            hipStream_t ls = ((j2 & 1) && la_slots(j2) == LA_SLOTS) ? la_stream2 : la_stream;
+            BARK_HIP_CHECK(hipStreamWaitEvent(ls, res->events[6 * j + 3], 0));
+            if ((r = launch_split(ls, j2, 0, j2 - 1, S2, 0, S2 + 1))) return r;
+            BARK_HIP_CHECK(hipEventRecord(res->events[6 * j2 + 2], ls));
         }
         return BARK_OK;
     }
@@ -1579,6 +1614,7 @@ struct Sweep {
         BARK_HIP_CHECK(hipStreamSynchronize(caller));
         if (res && res->helper) BARK_HIP_CHECK(hipStreamSynchronize(res->helper));
         if (res && res->helper2) BARK_HIP_CHECK(hipStreamSynchronize(res->helper2));
+        if (res && res->helper3) BARK_HIP_CHECK(hipStreamSynchronize(res->helper3));
         int r;
         auto span = [&](size_t a, size_t b_, float *acc) -> int {
             float ms = 0.f;
@@ -1668,6 +1704,7 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
     sw.nrb = nrb;
     sw.nrb_steps = nrb;
     sw.la_stream = ctx->helper2;
+    sw.la_stream2 = BARK_LA_STREAMS > 1 ? ctx->helper3 : ctx->helper2;
     sw.ncb = ncb;
     sw.fused = fused;
     sw.splitk = splitk;
@@ -1865,6 +1902,7 @@ static int leafspace_run(bark_ctx *ctx, const void *packed, const bark_pack_info
     sw.nrb = nrb;
     sw.nrb_steps = nrb;
     sw.la_stream = ctx->helper2;
+    sw.la_stream2 = BARK_LA_STREAMS > 1 ? ctx->helper3 : ctx->helper2;
     sw.ncb = ncb;
     sw.fused = false;
     sw.splitk = g.L.splitk;

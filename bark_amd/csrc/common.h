@@ -32,7 +32,8 @@ int fail(int code, const char *fmt, ...);
 struct bark_ctx {
     int device = 0;
     hipStream_t helper = nullptr;             // dense sweep: row launches beside the diag kernel
-    hipStream_t helper2 = nullptr;            // dense sweep: look-ahead launches of the split-K bulk
+    hipStream_t helper2 = nullptr;            // dense sweep: look-ahead launches of the split-K bulk (even steps) / pipelined rows
+    hipStream_t helper3 = nullptr;            // dense sweep: look-ahead bulk of the odd steps
     std::vector<hipEvent_t> events;           // fork / join events of the sweep (grown on demand, reused)
     std::vector<hipStream_t> chain_streams;   // multi-chain sampler step: one stream per chain (general shapes)
     std::vector<hipEvent_t> chain_done;

@@ -28,6 +28,11 @@ int ctx_events(bark_ctx *ctx, size_t n) {
         BARK_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         BARK_HIP_CHECK(hipStreamCreateWithPriority(&ctx->helper2, hipStreamNonBlocking, lo));
     }
+    if (!ctx->helper3) {
+        int lo = 0, hi = 0;
+        BARK_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        BARK_HIP_CHECK(hipStreamCreateWithPriority(&ctx->helper3, hipStreamNonBlocking, lo));
+    }
     while (ctx->events.size() < n) {
         hipEvent_t e;
         BARK_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -93,6 +98,10 @@ void bark_ctx_destroy(bark_ctx *ctx) {
     if (ctx->helper2) {
         (void)hipStreamSynchronize(ctx->helper2);
         (void)hipStreamDestroy(ctx->helper2);
+    }
+    if (ctx->helper3) {
+        (void)hipStreamSynchronize(ctx->helper3);
+        (void)hipStreamDestroy(ctx->helper3);
     }
     for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
     for (hipStream_t s : ctx->chain_streams) {
