@@ -851,6 +851,9 @@ __global__ __launch_bounds__(THREADS, 2) void row_kernel(Mats p, int j, int kdon
 // One launch over [0, j) is the plain split; the look-ahead schedule (Sweep::step) makes two: the bulk [0, j-1) one
 // step early and the last block row [j-1, j) on the critical path.
 // ---------------------------------------------------------------------------------------------
+// (Letting the last-block-row launch of a look-ahead step also add the bulk slabs and store T — no reduce launch on the
+// critical path — was measured much slower: one workgroup per tile streams its S slabs at a fraction of the rate the
+// 16 reduce workgroups per tile reach; one N = 16384 matrix 26.9 -> 36.7 ms.)
 __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(Mats p, int j, int n_right, int t_off, int n_tiles, int kb_lo,
                                                                   int kb_hi, int S, int s_off, int S_tot, double *slabs) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1237,6 +1240,9 @@ constexpr long TAIL_MAX_WGS = BARK_TAIL_MAX_WGS;  // ragged_tail: largest last r
 // under-filled steps can split K (build-time tuning constant; measured at N = 4096: B = 8 9.97 -> 5.62 ms, B = 16
 // 11.6 -> 9.4 ms, B = 32 16.9 -> 16.3 ms, no gain from B = 64 on)
 constexpr int SPLITK_LAYOUT_MAX_TILES = BARK_SPLITK_LAYOUT_MAX_TILES;
+#ifndef BARK_DIAG_SHARE_BESIDE_BULK
+#define BARK_DIAG_SHARE_BESIDE_BULK 2
+#endif
 #ifndef BARK_LA_STREAMS
 #define BARK_LA_STREAMS 2
 #endif
@@ -1385,8 +1391,16 @@ struct Sweep {
         int r;
         if (timed) diag_marks.push_back(ev.size());
         if ((r = mark_on(main))) return r;
-        hipLaunchKernelGGL(diag_kernel, dim3((unsigned)p.Bc), dim3(THREADS), p.Bc <= DIAG_EXCLUSIVE_MAX_BC ? DIAG_LDS_EXCLUSIVE : DIAG_LDS,
-                           main, p, j, nkb);
+        // a whole CU only while one can be had: beside a heavy look-ahead bulk (448 workgroups resident for ~250 us) no CU
+        // is empty, and the request would wait for the bulk to drain (kernel timeline of one N = 16384 matrix: diag 50 ->
+        // 200-300 us in the middle steps); there it asks for its 83 KiB and lands beside a single bulk workgroup
+        bool exclusive = p.Bc <= DIAG_EXCLUSIVE_MAX_BC;
+#if BARK_DIAG_SHARE_BESIDE_BULK == 1
+        if (lookahead(j + 1) && la_slots(j + 1) == LA_SLOTS) exclusive = false;
+#elif BARK_DIAG_SHARE_BESIDE_BULK == 2
+        if (lookahead(j + 1)) exclusive = false;
+#endif
+        hipLaunchKernelGGL(diag_kernel, dim3((unsigned)p.Bc), dim3(THREADS), exclusive ? DIAG_LDS_EXCLUSIVE : DIAG_LDS, main, p, j, nkb);
         BARK_LAUNCH_CHECK();
         return mark_on(main);
     }
