@@ -1234,11 +1234,14 @@ constexpr long LA_MIN_WORK = BARK_LA_MIN_WORK;
 #endif
 constexpr long TAIL_MAX_WGS = BARK_TAIL_MAX_WGS;  // ragged_tail: largest last round (workgroups) that is split over K
 #ifndef BARK_SPLITK_LAYOUT_MAX_TILES
-#define BARK_SPLITK_LAYOUT_MAX_TILES 1100
+#define BARK_SPLITK_LAYOUT_MAX_TILES 600
 #endif
-// Chunks with fewer tiles per block row than this reserve the slab scratch and materialise A, so that their
-// under-filled steps can split K (build-time tuning constant; measured at N = 4096: B = 8 9.97 -> 5.62 ms, B = 16
-// 11.6 -> 9.4 ms, B = 32 16.9 -> 16.3 ms, no gain from B = 64 on)
+// Chunks with fewer tiles per block row (matrices x block columns) than this reserve the slab scratch and materialise
+// A, so that their under-filled steps can split K; larger chunks run the pipelined schedule, whose two resident row
+// launches fill the chip.  Build-time tuning constant; the crossover sits between 512 and 640 tiles for every N
+// measured — split-K layout | pipelined: N = 4096, B = 16 9.1 | 9.0 ms, B = 20 12.5 | 11.3, B = 32 16.1 | 13.9;
+// N = 8192, B = 8 31.1 | 34.0, B = 12 54.2 | 50.4; N = 16384, B = 4 114.8 | 136.8; N = 2048, B = 32 3.04 | 3.17,
+// B = 40 3.61 | 3.49.
 constexpr int SPLITK_LAYOUT_MAX_TILES = BARK_SPLITK_LAYOUT_MAX_TILES;
 #ifndef BARK_DIAG_SHARE_BESIDE_BULK
 #define BARK_DIAG_SHARE_BESIDE_BULK 2
