@@ -1236,18 +1236,29 @@ constexpr long TAIL_MAX_WGS = BARK_TAIL_MAX_WGS;  // ragged_tail: largest last r
 #ifndef BARK_SPLITK_LAYOUT_MAX_TILES
 #define BARK_SPLITK_LAYOUT_MAX_TILES 600
 #endif
-// Chunks with fewer tiles per block row (matrices x block columns) than this reserve the slab scratch and materialise
-// A, so that their under-filled steps can split K; larger chunks run the pipelined schedule, whose two resident row
-// launches fill the chip.  Build-time tuning constant; the crossover sits between 512 and 640 tiles for every N
-// measured — split-K layout | pipelined: N = 4096, B = 16 9.1 | 9.0 ms, B = 20 12.5 | 11.3, B = 32 16.1 | 13.9;
-// N = 8192, B = 8 31.1 | 34.0, B = 12 54.2 | 50.4; N = 16384, B = 4 114.8 | 136.8; N = 2048, B = 32 3.04 | 3.17,
-// B = 40 3.61 | 3.49.
+#ifndef BARK_SPLITK_LAYOUT_MAX_WORK
+#define BARK_SPLITK_LAYOUT_MAX_WORK 5600
+#endif
+// Which chunks get the split-K layout (slab scratch reserved, A materialised, look-ahead schedule of Sweep::step) and
+// which the pipelined schedule (Sweep::step_pipelined, which splits K in its under-filled launches too).  The
+// look-ahead schedule has the shorter critical path per block step (diag + solve against diag + gw + K = 256 solve),
+// the pipelined one keeps the chip full; so the split-K layout is for sweeps bound by their critical path: fewer than
+// MAX_WORK (matrices x block columns) x block rows.  Build-time tuning constants; split-K layout | pipelined, ms:
+//   N = 4096:  B = 4 3.76 | 3.94, B = 6 5.57 | 5.21, B = 8 5.00 | 4.84, B = 16 9.12 | 7.39, B = 32 16.1 | 13.1
+//   N = 8192:  B = 1 7.33 | 7.71, B = 2 9.39 | 9.16, B = 3 17.2 | 15.0, B = 8 31.5 | 25.2
+//   N = 16384: B = 1 27.9 | 27.1, B = 4 115 | 95        N = 2048: B = 8 1.62 | 1.84, B = 16 2.03 | 2.11, B = 32 3.07 | 2.82
+//   N = 1024:  B = 24 0.78 | 0.97, B = 64 1.16 | 1.19
+// Below 8 block rows (no pipelining) the rule is the tile count alone.
 constexpr int SPLITK_LAYOUT_MAX_TILES = BARK_SPLITK_LAYOUT_MAX_TILES;
+constexpr int64_t SPLITK_LAYOUT_MAX_WORK = BARK_SPLITK_LAYOUT_MAX_WORK;
 #ifndef BARK_DIAG_SHARE_BESIDE_BULK
 #define BARK_DIAG_SHARE_BESIDE_BULK 2
 #endif
 #ifndef BARK_LA_STREAMS
 #define BARK_LA_STREAMS 2
+#endif
+#ifndef BARK_PIPE_SPLIT
+#define BARK_PIPE_SPLIT 1
 #endif
 #ifndef BARK_PIPE_STREAMS
 #define BARK_PIPE_STREAMS 2
@@ -1285,7 +1296,10 @@ Layout make_layout(int64_t N, int64_t C, int64_t m, int64_t Bc) {
     L.off_leafc = o;
     o = align256(o + (size_t)Bc * L.W * L.cpad * sizeof(uint32_t));
     L.off_slab = o;
-    L.splitk = Bc * (L.ncols / NB) < SPLITK_LAYOUT_MAX_TILES && L.npad / NB >= 4;
+    {
+        const int64_t nrb = L.npad / NB, tiles = Bc * (L.ncols / NB);
+        L.splitk = nrb >= 4 && (nrb < 8 ? tiles < SPLITK_LAYOUT_MAX_TILES : tiles * nrb < SPLITK_LAYOUT_MAX_WORK);
+    }
     // two slab sets (look-ahead: the bulk of step j+1 is accumulated while step j is reduced); a split step has fewer
     // than SPLITK_SLOTS / 2 tiles x matrices, S of at most SPLITK_SLOTS / that, plus one slab for the last block row
     o = align256(o + (size_t)2 * SLAB_SET_TILES * NB * NB * sizeof(double));  // every chunk: ragged last rounds split K too
@@ -1396,7 +1410,9 @@ struct Sweep {
         if ((r = mark_on(main))) return r;
         // a whole CU only while one can be had: beside a heavy look-ahead bulk (448 workgroups resident for ~250 us) no CU
         // is empty, and the request would wait for the bulk to drain (kernel timeline of one N = 16384 matrix: diag 50 ->
-        // 200-300 us in the middle steps); there it asks for its 83 KiB and lands beside a single bulk workgroup
+        // 200-300 us in the middle steps); there it asks for its 83 KiB and lands beside a single bulk workgroup.  (The
+        // pipelined schedule's row launches retire workgroups continuously: there the whole-CU request stays the
+        // better choice — one N = 16384 matrix 26.6 against 28.3 ms, N = 4096 x 8 4.87 against 5.34.)
         bool exclusive = p.Bc <= DIAG_EXCLUSIVE_MAX_BC;
 #if BARK_DIAG_SHARE_BESIDE_BULK == 1
         if (lookahead(j + 1) && la_slots(j + 1) == LA_SLOTS) exclusive = false;
@@ -1592,7 +1608,23 @@ struct Sweep {
         BARK_HIP_CHECK(hipStreamWaitEvent(st, res->events[6 * j + 3], 0));
         if (timed) panel_marks.push_back(ev.size());
         if ((r = mark_on(st))) return r;
-        if ((r = launch_rows(st, j, kdone(j), ncb - j - 1, tiles_of(j)))) return r;
+        // the last block rows have few tiles and the longest K: below half a round of workgroups the launch splits K
+        // (slabs + generating reduce, both on the bulk stream, off the critical path; slab sets alternate with j like
+        // the bulk streams).  N = 4096, B = 32: the last 8 steps took 3.5 of 13.9 ms.
+        const int k = kdone(j), nt = tiles_of(j);
+        int S = 1;
+        if (BARK_PIPE_SPLIT && k >= 2 && nt * p.Bc < SPLITK_SLOTS / 2) {
+            S = (2 * LA_SLOTS + nt * p.Bc) / (2 * nt * p.Bc);
+            if (S > k) S = k;
+            if (S > SPLITK_MAX) S = SPLITK_MAX;
+            while (S > 1 && S * nt * p.Bc > SPLITK_SLOTS) --S;
+        }
+        if (S >= 2) {
+            if ((r = launch_split(st, j, 0, k, S, 0, S))) return r;
+            if ((r = launch_reduce(st, j, S))) return r;
+        } else if ((r = launch_rows(st, j, k, ncb - j - 1, nt))) {
+            return r;
+        }
         if ((r = mark_on(st))) return r;
         BARK_HIP_CHECK(hipEventRecord(res->events[6 * j + 2], st));
         return BARK_OK;
