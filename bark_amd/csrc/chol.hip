@@ -1260,6 +1260,9 @@ constexpr int64_t SPLITK_LAYOUT_MAX_WORK = BARK_SPLITK_LAYOUT_MAX_WORK;
 #ifndef BARK_PIPE_SPLIT
 #define BARK_PIPE_SPLIT 1
 #endif
+#ifndef BARK_PIPE_MIN_NRB
+#define BARK_PIPE_MIN_NRB 8
+#endif
 #ifndef BARK_PIPE_STREAMS
 #define BARK_PIPE_STREAMS 2
 #endif
@@ -1298,7 +1301,7 @@ Layout make_layout(int64_t N, int64_t C, int64_t m, int64_t Bc) {
     L.off_slab = o;
     {
         const int64_t nrb = L.npad / NB, tiles = Bc * (L.ncols / NB);
-        L.splitk = nrb >= 4 && (nrb < 8 ? tiles < SPLITK_LAYOUT_MAX_TILES : tiles * nrb < SPLITK_LAYOUT_MAX_WORK);
+        L.splitk = nrb >= 4 && (nrb < BARK_PIPE_MIN_NRB ? tiles < SPLITK_LAYOUT_MAX_TILES : tiles * nrb < SPLITK_LAYOUT_MAX_WORK);
     }
     // two slab sets (look-ahead: the bulk of step j+1 is accumulated while step j is reduced); a split step has fewer
     // than SPLITK_SLOTS / 2 tiles x matrices, S of at most SPLITK_SLOTS / that, plus one slab for the last block row
@@ -1761,7 +1764,7 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
     // B = 40 +15 %, 64 +7 %, 96 +9 %, 160 +5 %, 192 +4 %; N = 8192, B = 32 +7 %; N = 2048, B = 128..192 +5 %), but not
     // when Bc is a multiple of the 256 CUs — every round is then full or exactly half full, and the K = 256 solve and
     // gw_kernel only cost (B = 256: -1.5 % at N = 4096, -2 % at N = 1024..2048) — nor for fewer than 8 block rows.
-    const bool pipeline_ok = BARK_PIPELINE != 0 && !splitk && nrb >= 8;  // decided per chunk below
+    const bool pipeline_ok = BARK_PIPELINE != 0 && !splitk && nrb >= BARK_PIPE_MIN_NRB;  // decided per chunk below
     sw.rep = rep;
     sw.slabs = slabs;
     sw.timed = timing != nullptr;
@@ -1988,6 +1991,7 @@ static int leafspace_run(bark_ctx *ctx, const void *packed, const bark_pack_info
         const char *packed_c = static_cast<const char *>(packed) + (size_t)c0 * m * info->stride * 16;
         p.info = info_out + c0;
         p.Bc = (int)bc;
+        sw.pipelined = BARK_PIPELINE != 0 && !g.L.splitk && nrb >= BARK_PIPE_MIN_NRB && (bc % 256) != 0;  // as the dense entry
         if ((rc = walk_one_hot(packed_c, &sub, X, N, d, (int)g.W, codes, ctx->fault, caller))) return rc;
         rc = leafspace_prepare(codes, (int)g.W, (int)g.npad, planes, (int)g.R, (int)g.Rpad, noise + c0,
                                use_scale ? scale + c0 : nullptr, (int)m, (int)bc, p.A, p.ld, p.bstride, y, (int)N, p.yz,

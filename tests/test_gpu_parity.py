@@ -649,6 +649,12 @@ def test_leafspace_mll_equals_dense_and_reference(B):
                             method="leafspace")
     want = B.orc.batched_mll(bushy, [0.1], [1.0], Xc, yc, np.full(6, 2), include_scale=True, include_2pi=True)
     assert np.allclose(got, want, rtol=MLL_RTOL, atol=MLL_ATOL)
+    # 40 bushy forests at once: 13 block rows x 40 matrices in leaf space — the pipelined schedule of the sweep
+    many = np.concatenate([B.syn.full_binary_forest(50, 6, 5, rng)[None] for _ in range(40)])
+    nz, sc = np.linspace(0.05, 0.3, 40), np.linspace(0.7, 1.4, 40)
+    leaf40 = B.fit.batched_mll(many, nz, sc, Xc, yc, np.full(6, 2), include_scale=True, include_2pi=True, method="leafspace")
+    dense40 = B.fit.batched_mll(many, nz, sc, Xc, yc, np.full(6, 2), include_scale=True, include_2pi=True)
+    assert np.allclose(leaf40, dense40, rtol=1e-10, atol=1e-8), np.abs(leaf40 - dense40).max()
     with pytest.raises(ValueError):
         B.fit.batched_mll(bushy, [0.1], [1.0], Xc, yc, np.full(6, 2), include_scale=True, include_2pi=True, method="lu")
     # posterior in leaf space: golden (reference arithmetic), then a larger mixed problem against the dense path
