@@ -24,6 +24,17 @@
 // appended as extra block columns, so the same sweep yields V = U^-T K_Xx; then mu = V'z,
 // var = scale - colsumsq(V), and optionally the full covariance / K_s^-1 = V'V (vtv_kernel).
 //
+// Three schedules of those kernels (Sweep, below), chosen per chunk of resident matrices:
+//   plain       diag(j) || row(j), then solve(j).  Chunks whose size is a multiple of the 256 CUs (every round of row
+//               workgroups full) and matrices of fewer than 8 block rows.
+//   pipelined   row(j) covers k < j-1 only and is launched two steps ahead on the helper streams; the last block row is
+//               applied by its consumers: solve_kernel<1> (one K = 256 product with the stacked [-U[j-1,j] W_j ; W_j])
+//               and diag_kernel (two block rows, and the -U[j-1,j] W_j block in its epilogue).  Under-filled launches
+//               split K.  Everything else that is not bound by its critical path.
+//   look-ahead  split-K layout (A materialised, slab scratch): the bulk of step j+2's K range (split into slabs) is
+//               launched after solve(j); diag(j) || the last block row's slab, reduce, solve(j) remain on the critical
+//               path.  Few small matrices (one N = 4096 matrix: 2.5 ms).
+//
 // Why left-looking: every U tile is written once and each trailing tile is accumulated in
 // registers over the whole K range, instead of a read-modify-write of the trailing matrix per
 // step.  Why lock step over the batch: the serial 128x128 potrf/inverse of one matrix occupies
@@ -253,7 +264,7 @@ struct Mats {
     double *A;            // (Bc, Npad, ld)
     long ld, bstride;
     double *W;            // (Bc, 256, 128)  rows 128..255: W_j = inverse of the current diagonal factor; rows 0..127:
-                          //                 -U[j-1,j] W_j (gw_kernel; pipelined schedule only)
+                          //                 -U[j-1,j] W_j (diag_kernel's epilogue; pipelined schedule only)
     double *yz;           // (Bc, Npad)      y on entry, z = U^-T y on exit
     double *accum;        // (Bc, 2)         quad, logdet
     int32_t *info;        // (Bc,)
@@ -534,9 +545,50 @@ __device__ __forceinline__ void diag_update(const double *__restrict__ tile, lon
     }
 }
 
+// G_j = U[j-1,j] W_j for diag_kernel's epilogue (pipelined schedule; W_j upper triangular: column block cbk sums the
+// row blocks rbk <= cbk).  Wave w owns the 16-row blocks 2w, 2w+1 of G.  A fragments (U[j-1,j], 16 rows x 4 columns per
+// MFMA) come straight from L2 — solve(j-1) wrote the tile just before — and the B fragments are the sub-blocks of W_j
+// still in S.  Out: Gb[k][r] = -G.  
+__device__ __forceinline__ void diag_g(const double *__restrict__ Up, long ld, const double *S, double *__restrict__ Gb, int wave_u,
+                                    int lr, int lk) {
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        const int kr = wave_u * 2 + h;
+        const double *urow = Up + (size_t)(kr * SB + lr) * ld + lk;
+        f64x4 g[NSB];
+#pragma unroll
+        for (int cbk = 0; cbk < NSB; ++cbk) g[cbk] = (f64x4){0.0, 0.0, 0.0, 0.0};
+        double a[4], an[4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) a[q4] = urow[q4 * 4];
+#pragma unroll
+        for (int rbk = 0; rbk < NSB; ++rbk) {  // k' ascending for every element of G
+            if (rbk + 1 < NSB) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) an[q4] = urow[(rbk + 1) * SB + q4 * 4];
+            }
+#pragma unroll
+            for (int cbk = rbk; cbk < NSB; ++cbk) {
+                const double *wb = S + blk_off(rbk, cbk);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+                    g[cbk] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q4], wb[(q4 * 4 + lk) * SB + lr], g[cbk], 0, 0, 0);
+            }
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) a[q4] = an[q4];
+            __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads of later row blocks from being hoisted (spills)
+        }
+#pragma unroll
+        for (int cbk = 0; cbk < NSB; ++cbk)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) Gb[(size_t)(kr * SB + lk + 4 * v) * NB + cbk * SB + lr] = -g[cbk][v];
+    }
+}
+
 // nkb: trailing block rows of U still to be applied to the stored diagonal tile, D = P - sum_{j-nkb <= k < j} U[k,j]'U[k,j]
 // (1 in the plain schedule, 2 in the pipelined one, 0 for j == 0).
-__global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb) {
+// want_g (pipelined schedule): also rows 0..127 of Mats::W := -U[j-1,j] W_j, the dense half of solve_kernel<1>'s left operand.
+__global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb, int want_g) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, b = blockIdx.x;
     const Lane q = lane_of(tid);
@@ -679,6 +731,9 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
             for (int cbk = 0; cbk < NSB; ++cbk)
                 Wb[(size_t)(rbk * SB + r) * NB + cbk * SB + c] = rbk <= cbk ? S[blk_off(rbk, cbk) + tid] : 0.0;
     }
+
+    if (want_g)  // workgroup-uniform
+        diag_g(Ab + (size_t)(j - 1) * NB * p.ld + (size_t)j * NB, p.ld, S, p.W + (size_t)b * W_STRIDE, wave_u, lr, lk);
 
     // --- z_j = W_j' y_j ; quad += |z_j|^2 ; logdet += 2 sum log u_kk ----------------------------
     // thread (c, half) sums the sub-block rows 4*half .. 4*half+3 of column c (only sub-blocks on or above the block
@@ -942,53 +997,11 @@ __global__ __launch_bounds__(THREADS) void panel_reduce_kernel(Mats p, int j, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// gw_kernel (pipelined schedule): rows 0..127 of Mats::W := -G_j, G_j = U[j-1,j] W_j (128 x 128; W_j upper triangular,
-// so column r only sums k' <= r).  Grid (4, Bc): workgroup g owns the rows k in [32 g, 32 g + 32) of G, wave w the
-// columns [32 w, 32 w + 32).  The 32 x 128 slice of U[j-1,j] goes through LDS (row stride 130: the A-fragment read,
-// 16 rows x 4 columns per wave, is conflict-free per half wave); W_j is read from L2 in the B-fragment pattern.
-// ---------------------------------------------------------------------------------------------
-constexpr int GW_ROWS = 32, GW_LD = NB + 2;
-__global__ __launch_bounds__(THREADS) void gw_kernel(Mats p, int j) {
-    __shared__ double Us[GW_ROWS * GW_LD];
-    const int tid = threadIdx.x, g = blockIdx.x, b = blockIdx.y;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane & 15, lk = lane >> 4;
-    const double *Ub = p.A + (size_t)b * p.bstride + ((size_t)(j - 1) * NB + g * GW_ROWS) * p.ld + (size_t)j * NB;
-    {
-        const int r = tid >> 3, c0 = (tid & 7) * 16;  // 16 consecutive doubles of one row per thread
-        const f64x2 *src = reinterpret_cast<const f64x2 *>(Ub + (size_t)r * p.ld + c0);
-        f64x2 *dst = reinterpret_cast<f64x2 *>(Us + r * GW_LD + c0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) dst[i] = src[i];
-    }
-    __syncthreads();
-    const double *Wj = w_block(p, b);
-    double *out = p.W + (size_t)b * W_STRIDE + (size_t)g * GW_ROWS * NB;
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        const int c0 = wave * 32 + ct * 16;
-        f64x4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
-        const int nkk = (c0 + 16) / 4;  // k' < c0 + 16: below that row W_j's columns c0.. are zero
-#pragma unroll 8
-        for (int kk = 0; kk < nkk; ++kk) {
-            const double w = Wj[(size_t)(kk * 4 + lk) * NB + c0 + lr];
-            const double u0 = Us[lr * GW_LD + kk * 4 + lk], u1 = Us[(16 + lr) * GW_LD + kk * 4 + lk];
-            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, w, a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(u1, w, a1, 0, 0, 0);
-        }
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            out[(size_t)(lk + 4 * v) * NB + c0 + lr] = -a0[v];
-            out[(size_t)(16 + lk + 4 * v) * NB + c0 + lr] = -a1[v];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // solve_kernel: U[j,i] = W_j' T[j,i] for every tile right of the diagonal; y_i -= U[j,i]' z_j.
 // DEF == 1 (pipelined schedule): the stored tile lacks the last block row of its sum, T = T' - U[j-1,j]'U[j-1,i], and
 //   U[j,i] = W_j' T' - (U[j-1,j] W_j)' U[j-1,i] = [-G_j ; W_j]' [U[j-1,i] ; T'[j,i]]
 // is ONE K = 256 product: the right operand is the contiguous 256-row panel of column block i starting at block row
-// j-1, the left one the stacked (256 x 128) block Mats::W that gw_kernel and diag_kernel fill.
+// j-1, the left one the stacked (256 x 128) block Mats::W that diag_kernel fills.
 // ---------------------------------------------------------------------------------------------
 template <int DEF>
 __global__ __launch_bounds__(THREADS, 2) void solve_kernel(Mats p, int j, int n_right) {
@@ -1241,7 +1254,7 @@ constexpr long TAIL_MAX_WGS = BARK_TAIL_MAX_WGS;  // ragged_tail: largest last r
 #endif
 // Which chunks get the split-K layout (slab scratch reserved, A materialised, look-ahead schedule of Sweep::step) and
 // which the pipelined schedule (Sweep::step_pipelined, which splits K in its under-filled launches too).  The
-// look-ahead schedule has the shorter critical path per block step (diag + solve against diag + gw + K = 256 solve),
+// look-ahead schedule has the shorter critical path per block step (diag + solve against a longer diag + a K = 256 solve),
 // the pipelined one keeps the chip full; so the split-K layout is for sweeps bound by their critical path: fewer than
 // MAX_WORK (matrices x block columns) x block rows.  Build-time tuning constants; split-K layout | pipelined, ms:
 //   N = 4096:  B = 4 3.76 | 3.94, B = 6 5.57 | 5.21, B = 8 5.00 | 4.84, B = 16 9.12 | 7.39, B = 32 16.1 | 13.1
@@ -1407,7 +1420,7 @@ struct Sweep {
         return BARK_OK;
     }
 
-    int launch_diag(int j, int nkb) {
+    int launch_diag(int j, int nkb, int want_g = 0) {
         int r;
         if (timed) diag_marks.push_back(ev.size());
         if ((r = mark_on(main))) return r;
@@ -1422,7 +1435,7 @@ struct Sweep {
 #elif BARK_DIAG_SHARE_BESIDE_BULK == 2
         if (lookahead(j + 1)) exclusive = false;
 #endif
-        hipLaunchKernelGGL(diag_kernel, dim3((unsigned)p.Bc), dim3(THREADS), exclusive ? DIAG_LDS_EXCLUSIVE : DIAG_LDS, main, p, j, nkb);
+        hipLaunchKernelGGL(diag_kernel, dim3((unsigned)p.Bc), dim3(THREADS), exclusive ? DIAG_LDS_EXCLUSIVE : DIAG_LDS, main, p, j, nkb, want_g);
         BARK_LAUNCH_CHECK();
         return mark_on(main);
     }
@@ -1593,10 +1606,10 @@ struct Sweep {
     // ---- pipelined schedule (chunks with enough matrices to fill the chip, i.e. not in the split-K layout) -----------
     // The row launch of block row j covers only the block rows k < j-1 of its K range ("bulk"), which are final once
     // solve(j-2) has retired; the last block row is applied by the consumers — solve_kernel<1>(j) (one K = 256 product,
-    // see there) and diag_kernel(j+1) (two block rows instead of one).  So bulk(j+2) runs beside diag(j+1), gw(j+1)
+    // see there) and diag_kernel(j+1) (two block rows instead of one).  So bulk(j+2) runs beside diag(j+1)
     // and the HBM-bound solve(j+1) instead of waiting for them, and — alternating between the two helper streams —
     // beside the ragged last round of bulk(j+1):
-    //   caller's stream  diag(j) -> gw(j) -> [wait bulk(j)] solve(j) -> diag(j+1) -> ...
+    //   caller's stream  diag(j) -> [wait bulk(j)] solve(j) -> diag(j+1) -> ...
     //   helper streams   bulk(j+2) after solve(j)
     // Every bulk launch is awaited on the caller's stream at its own step, so the pattern stays fork/join (capturable).
     int kdone(int j) const { return j > 0 ? j - 1 : 0; }
@@ -1640,12 +1653,8 @@ struct Sweep {
             if ((r = launch_bulk(1))) return r;
         }
         // the stored P_jj comes from the row launch of block row j-1: block rows kdone(j-1) .. j-1 are still to apply
-        if ((r = launch_diag(j, j > 0 ? j - kdone(j - 1) : 0))) return r;
         const bool deferred = j > kdone(j);
-        if (deferred && n_right > 0) {
-            hipLaunchKernelGGL(gw_kernel, dim3(NB / GW_ROWS, (unsigned)bc), dim3(THREADS), 0, main, p, j);
-            BARK_LAUNCH_CHECK();
-        }
+        if ((r = launch_diag(j, j > 0 ? j - kdone(j - 1) : 0, deferred && n_right > 0))) return r;
         if (has_bulk(j)) BARK_HIP_CHECK(hipStreamWaitEvent(main, res->events[6 * j + 2], 0));
         if (n_right > 0) {
             if (timed) solve_marks.push_back(ev.size());
@@ -1763,7 +1772,7 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
     // Pipelined schedule: pays whenever the plain schedule leaves ragged rounds of workgroups (measured at N = 4096:
     // B = 40 +15 %, 64 +7 %, 96 +9 %, 160 +5 %, 192 +4 %; N = 8192, B = 32 +7 %; N = 2048, B = 128..192 +5 %), but not
     // when Bc is a multiple of the 256 CUs — every round is then full or exactly half full, and the K = 256 solve and
-    // gw_kernel only cost (B = 256: -1.5 % at N = 4096, -2 % at N = 1024..2048) — nor for fewer than 8 block rows.
+    // the longer diag kernel only cost (B = 256: -1.5 % at N = 4096, -2 % at N = 1024..2048) — nor for fewer than 8 block rows.
     const bool pipeline_ok = BARK_PIPELINE != 0 && !splitk && nrb >= BARK_PIPE_MIN_NRB;  // decided per chunk below
     sw.rep = rep;
     sw.slabs = slabs;
