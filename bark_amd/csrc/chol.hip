@@ -1276,6 +1276,9 @@ constexpr int64_t SPLITK_LAYOUT_MAX_WORK = BARK_SPLITK_LAYOUT_MAX_WORK;
 #ifndef BARK_PIPE_MIN_NRB
 #define BARK_PIPE_MIN_NRB 8
 #endif
+#ifndef BARK_PIPE_ALL_SIZES
+#define BARK_PIPE_ALL_SIZES 0
+#endif
 #ifndef BARK_PIPE_STREAMS
 #define BARK_PIPE_STREAMS 2
 #endif
@@ -1770,9 +1773,11 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
     sw.fused = fused;
     sw.splitk = splitk;
     // Pipelined schedule: pays whenever the plain schedule leaves ragged rounds of workgroups (measured at N = 4096:
-    // B = 40 +15 %, 64 +7 %, 96 +9 %, 160 +5 %, 192 +4 %; N = 8192, B = 32 +7 %; N = 2048, B = 128..192 +5 %), but not
-    // when Bc is a multiple of the 256 CUs — every round is then full or exactly half full, and the K = 256 solve and
-    // the longer diag kernel only cost (B = 256: -1.5 % at N = 4096, -2 % at N = 1024..2048) — nor for fewer than 8 block rows.
+    // B = 40 +15 %, 64 +7 %, 96 +9 %, 160 +5 %, 192 +4 %; N = 8192, B = 32 +7 %; N = 2048, B = 128..192 +5 %).  When Bc
+    // is a multiple of the 256 CUs every round of the plain schedule is full or exactly half full; the two then tie at
+    // N = 4096 (93.6 | 93.7 ms at B = 256), the plain one wins beyond (B = 512: 186.6 | 188.6; N = 8192, B = 256:
+    // 696 | 711) and the pipelined one up to 16 block rows (N = 2048: 14.1 | 13.8, N = 1024: 2.65 | 2.56).  Fewer than 8
+    // block rows: no difference measured (N = 512..896), plain.
     const bool pipeline_ok = BARK_PIPELINE != 0 && !splitk && nrb >= BARK_PIPE_MIN_NRB;  // decided per chunk below
     sw.rep = rep;
     sw.slabs = slabs;
@@ -1860,7 +1865,7 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
     if ((rc = sw.mark_on(caller))) return rc;
     for (int64_t c0 = 0; c0 < B; c0 += Bc) {  // chunks of Bc resident matrices, one after the other
         const int64_t bc = (B - c0 < Bc) ? (B - c0) : Bc;
-        sw.pipelined = pipeline_ok && (bc % 256) != 0;
+        sw.pipelined = pipeline_ok && (BARK_PIPE_ALL_SIZES != 0 || (bc % 256) != 0 || nrb <= 16);
         if ((rc = prologue(c0, bc))) return rc;
         for (int j = 0; j < nrb; ++j)
             if ((rc = sw.step(j))) return rc;
@@ -2000,7 +2005,7 @@ static int leafspace_run(bark_ctx *ctx, const void *packed, const bark_pack_info
         const char *packed_c = static_cast<const char *>(packed) + (size_t)c0 * m * info->stride * 16;
         p.info = info_out + c0;
         p.Bc = (int)bc;
-        sw.pipelined = BARK_PIPELINE != 0 && !g.L.splitk && nrb >= BARK_PIPE_MIN_NRB && (bc % 256) != 0;  // as the dense entry
+        sw.pipelined = BARK_PIPELINE != 0 && !g.L.splitk && nrb >= BARK_PIPE_MIN_NRB && (BARK_PIPE_ALL_SIZES != 0 || (bc % 256) != 0 || nrb <= 16);  // as the dense entry
         if ((rc = walk_one_hot(packed_c, &sub, X, N, d, (int)g.W, codes, ctx->fault, caller))) return rc;
         rc = leafspace_prepare(codes, (int)g.W, (int)g.npad, planes, (int)g.R, (int)g.Rpad, noise + c0,
                                use_scale ? scale + c0 : nullptr, (int)m, (int)bc, p.A, p.ld, p.bstride, y, (int)N, p.yz,
