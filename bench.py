@@ -437,7 +437,7 @@ def worker(args) -> int:
     wl.run(timing)
     breakdown = {k: round(float(getattr(timing, k)), 3) for k in ("total_ms", "gram_ms", "chol_ms", "diag_ms", "panel_ms", "solve_ms")}
     kern = {}
-    for name, ms_key, n_key, fl_key in (("panel_kernel", "panel_ms", "n_panel_launches", "panel_flops"),
+    for name, ms_key, n_key, fl_key in (("row_kernel", "panel_ms", "n_panel_launches", "panel_flops"),
                                         ("solve_kernel", "solve_ms", "n_solve_launches", "solve_flops"),
                                         ("diag_kernel", "diag_ms", "n_diag_launches", None)):
         nl = int(getattr(timing, n_key))
