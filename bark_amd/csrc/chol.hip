@@ -1648,6 +1648,10 @@ struct Sweep {
         BARK_HIP_CHECK(hipEventRecord(res->events[6 * j + 2], st));
         return BARK_OK;
     }
+    // (Tried for sweeps bound by their critical path and dropped: applying the last block row by a K = 128 row launch
+    // that updates the stored tiles in place beside diag(j), followed by the plain solve — max(diag, update) + solve<0>
+    // looked shorter than diag + solve<1>, but the update launch competes with the resident row launches like the
+    // solve does: N = 4096, B = 16 7.27 -> 7.98 ms, one N = 16384 matrix 26.3 -> 27.7.)
     int step_pipelined(int j) {
         const int bc = p.Bc, n_right = ncb - j - 1;
         int r;
