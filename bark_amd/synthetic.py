@@ -129,6 +129,27 @@ def full_binary_forest(m, d, depth, rng, node_limit=100):
     return forest
 
 
+def full_binary_forests(B, m, d, depth, rng, node_limit=100):
+    """B forests of complete binary trees (the vectorised form of `full_binary_forest`, for benchmark-sized batches);
+    SURVEY §8d's stress variant of c2/c3 uses depth 5: 63 nodes, 32 leaves per tree."""
+    n_nodes = 2 ** (depth + 1) - 1
+    assert n_nodes <= node_limit
+    forest = np.zeros((B, m, node_limit), dtype=NODE_RECORD_DTYPE)
+    i = np.arange(n_nodes)
+    dep = np.floor(np.log2(i + 1)).astype(np.uint32)
+    leaf = dep == depth
+    f = forest[:, :, :n_nodes]
+    f["is_leaf"] = leaf
+    f["feature_idx"] = np.where(leaf, 0, rng.integers(0, d, size=(B, m, n_nodes)))
+    f["threshold"] = np.where(leaf, 0.0, rng.uniform(0.05, 0.95, size=(B, m, n_nodes)))
+    f["left"] = np.where(leaf, 0, 2 * i + 1)
+    f["right"] = np.where(leaf, 0, 2 * i + 2)
+    f["parent"] = np.where(i == 0, 0xFFFFFFFF, (i - 1) // 2).astype(np.uint32)
+    f["depth"] = dep
+    f["active"] = 1
+    return forest
+
+
 def unit_cube_problem(N, d, seed):
     """SURVEY §8d c2/c3 inputs: X ~ U[0,1)^(N x d), y = standardised N(0,1), all-continuous domain."""
     rng = np.random.default_rng(seed)

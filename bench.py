@@ -183,7 +183,7 @@ class Workload:
         from bark_amd.forest import PackedForest
 
         self.N, self.d, self.m, self.B, self.C = N, d, m, B, C
-        if problem == "unit":
+        if problem in ("unit", "stress"):
             X, y, bounds, ft = synthetic.unit_cube_problem(N, d, seed=seed_base)
             cand = None
         else:  # c5: mixed categorical + integer + continuous
@@ -191,7 +191,10 @@ class Workload:
             cand = synthetic.mixed_problem(C, seed=seed_base + 1)[0] if C else None
             self.d = d = X.shape[1]
         self.X, self.y, self.ft = X, y, ft
-        self.forests = synthetic.sample_prior_forests(B, m, bounds, ft, seed=seed_base + rank_offset)
+        if problem == "stress":  # SURVEY §8d stress variant: complete depth-5 trees, 32 leaves each (prior trees average 2.4)
+            self.forests = synthetic.full_binary_forests(B, m, d, 5, np.random.default_rng(seed_base + rank_offset))
+        else:
+            self.forests = synthetic.sample_prior_forests(B, m, bounds, ft, seed=seed_base + rank_offset)
         rng = np.random.default_rng(seed_base + 7919 * ((noise_seed if noise_seed is not None else rank_offset) + 1))
         self.noise = rng.uniform(0.05, 0.15, size=B)
         self.lib = lib = _lib.lib()
@@ -557,6 +560,8 @@ def extras(args, wl, result, mll_host):
             cfgs.append(row)
 
         entry("c2: N=1024 d=8 m=50, single forest", Workload(1024, 8, m, 1, 1024, 0), 20, graph=True)
+        entry("c3 stress variant: N=4096, 256 forests of 50 complete depth-5 trees (32 leaves per tree)",
+              Workload(4096, d, m, 256, N, 0, problem="stress"), 3)
         entry("c4 per-GPU share: N=4096, 64 forests", Workload(4096, d, m, 64, N, 0), 5)
         entry("small batch: N=4096, 16 forests", Workload(4096, d, m, 16, N, 0), 5)
         entry("small batch: N=4096, 8 forests", Workload(4096, d, m, 8, N, 0), 5)
