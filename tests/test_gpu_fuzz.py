@@ -49,3 +49,34 @@ def test_mll_and_posterior_across_schedules(N, B, m, C, chunk):
     assert np.allclose(mu[pick], mu0, rtol=1e-9, atol=1e-9) and np.allclose(var[pick], var0, rtol=1e-9, atol=1e-9)
     want = orc.batched_mll(F[pick], noise[pick], scale[pick], X, y, ft, include_scale=True, include_2pi=False)
     assert np.allclose(mll[pick], want, rtol=MLL_RTOL, atol=MLL_ATOL)
+
+
+def test_inverse_export_through_the_pipelined_schedule():
+    """`batched_kernel_inverse` (N identity columns appended: 18 block columns at N = 1100) with enough forests for the
+    pipelined schedule, and a batch whose chunks take different schedules (256 = plain, the remaining 44 = pipelined)."""
+    import bark_amd.fitting as fit
+    from bark_amd import synthetic as syn
+    from oracle import oracle as orc
+
+    N, B, m = 1100, 40, 30
+    X, y, bounds, ft = syn.mixed_problem(N, seed=77)
+    F = syn.sample_prior_forests(B, m, bounds, ft, seed=78)
+    rng = np.random.default_rng(79)
+    noise, scale = rng.uniform(0.05, 0.3, B), rng.uniform(0.6, 1.5, B)
+    K_inv, K_inv_y, logdet = fit.batched_kernel_inverse(F, noise, scale, X, y, ft, no_null=False)
+    for b in (0, 17, 39):
+        K = orc.forest_gram_matrix(F[b], X, X, ft)
+        K_s = scale[b] * K + (1e-6 + noise[b]) * np.eye(N)
+        assert np.allclose(K_inv[b] @ K_s, np.eye(N), atol=1e-8)
+        assert np.allclose(K_inv_y[b], np.linalg.solve(K_s, y[:, 0]), rtol=1e-8, atol=1e-9)
+        assert np.isclose(logdet[b], np.linalg.slogdet(K_s)[1], rtol=1e-10)
+
+    B2 = 300
+    F2 = syn.sample_prior_forests(B2, m, bounds, ft, seed=80)
+    nz = np.random.default_rng(81).uniform(0.05, 0.3, B2)
+    whole = fit.batched_mll(F2, nz, None, X, y, ft, include_scale=False, include_2pi=True, chunk=256)
+    parts = fit.batched_mll(F2, nz, None, X, y, ft, include_scale=False, include_2pi=True, chunk=100)
+    assert np.allclose(whole, parts, rtol=1e-12, atol=0)
+    pick = [0, 255, 256, 299]
+    want = orc.batched_mll(F2[pick], nz[pick], None, X, y, ft, include_scale=False, include_2pi=True)
+    assert np.allclose(whole[pick], want, rtol=MLL_RTOL, atol=MLL_ATOL)
