@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""One-off randomised hunt over shapes of the dense sweep (not part of the test-suite): python3 tools/fuzz_shapes.py [n] [seed]."""
+"""One-off randomised hunt over shapes of the dense sweep (not part of the test-suite): python3 tests/fuzz/fuzz_shapes.py [n] [seed]; it checks against the oracle, hence under tests/."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 from test_gpu_fuzz import test_mll_and_posterior_across_schedules as check
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)

@@ -1,3 +1,5 @@
+"""One-off randomised check of the device-side Metropolis sweep (ChainBatch.sweep_trees) against the host loop and the oracle
+(not collected by pytest): python3 tests/fuzz/fuzz_sweep.py from the repo root, on a GPU box."""
 import os, sys, numpy as np
 sys.path.insert(0, os.getcwd())
 import bark_amd.fitting as fit
