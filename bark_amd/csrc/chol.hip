@@ -852,13 +852,14 @@ __device__ __forceinline__ void form_tile(const f64x4 (&acc)[4][4], const Mats &
 // y_i -= U[j,i]' z_j in a fixed summation order: per 16-row tile rt, p[rt][c] = sum of the lane's four rows (fma chain), then over the four lane groups
 // (xor 16, xor 32); then y[c] -= ((p[0][c] + p[1][c]) + ...) + p[7][c].  `o` = the wave's U values of row tile rt,
 // columns col0 + nt*16 + lr; z = z_j; part = LDS [8][128].
-__device__ __forceinline__ void y_partial(const f64x4 (&o)[4], int rt, const double *__restrict__ z, double *part, int col0,
+template <int NT>
+__device__ __forceinline__ void y_partial(const f64x4 (&o)[NT], int rt, const double *__restrict__ z, double *part, int col0,
                                           const Lane &q) {
     double zr[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) zr[v] = z[rt * 16 + q.lk + 4 * v];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
         double s = 0.0;
 #pragma unroll
         for (int v = 0; v < 4; ++v) s = fma(o[nt][v], zr[v], s);
@@ -1036,9 +1037,80 @@ __global__ __launch_bounds__(THREADS, 2) void solve_kernel(Mats p, int j, int n_
     double *part = lds;  // [8][128]; the GEMM ended with a barrier
     const double *zb = p.yz + (size_t)b * p.nrb * NB + (size_t)j * NB;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) y_partial(acc[mt], rt[mt], zb, part, q.wc * 64, q);
+    for (int mt = 0; mt < 4; ++mt) y_partial<4>(acc[mt], rt[mt], zb, part, q.wc * 64, q);
     __syncthreads();
     if (tid < NB) y_commit(part, p.yz + (size_t)b * p.nrb * NB + (size_t)cb * NB, tid);
+}
+
+// ---------------------------------------------------------------------------------------------
+// solve_narrow_kernel: the same U[j,i] = W_j' T[j,i] with a tile's 128 columns shared out over 4 / NT workgroups (32 NT
+// columns each, 16 NT per wave) — for the critical path of lone matrices, where solve_kernel is one workgroup per tile on
+// an otherwise idle chip and its 2.4 MFLOP of MFMA work on ONE CU (7.7 us of an 18 us launch) is what takes the time.
+// Each workgroup still stages the whole k-rows of T (L2-resident: the reduce kernel just wrote them).  Per column the
+// arithmetic and its order are those of solve_kernel: identical results.
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(THREADS, 2) void solve_narrow_kernel(Mats p, int j, int n_right) {
+    constexpr int PARTS = 4 / NT, WCOLS = 32 * NT, nk = NB / BK;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x;
+    int b, tp;
+    if (!xcd_map(blockIdx.x, n_right * PARTS, p.Bc, b, tp)) return;
+    const Lane q = lane_of(tid);
+    const int t = tp / PARTS, c_off = (tp - t * PARTS) * WCOLS + q.wc * 16 * NT;  // this wave's first column in the tile
+    const int cb = j + 1 + t;
+    double *tile = p.A + (size_t)b * p.bstride + (size_t)j * NB * p.ld + (size_t)cb * NB;
+    const double *Wb = p.W + (size_t)b * W_STRIDE + (size_t)NB * NB;
+    const int wr_u = __builtin_amdgcn_readfirstlane(q.wr);
+    const int rt[4] = {wr_u ? 1 : 0, wr_u ? 2 : 3, wr_u ? 5 : 4, wr_u ? 6 : 7};
+    f64x4 acc[4][NT];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    stage_dma(Wb, NB, tile, p.ld, 0, lds, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) stage_dma(Wb, NB, tile, p.ld, kt + 1, lds + ((kt + 1) & 1) * STAGE, wave, lane);
+        const double *As = lds + (kt & 1) * STAGE;
+        const double *Bs = As + BK * LDS_LD;
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            double bf[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bf[nt] = Bs[(kk * 4 + q.lk) * LDS_LD + c_off + nt * 16 + q.lr];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                if (kt <= rt[mt]) {  // wave-uniform
+                    const double a = As[(kk * 4 + q.lk) * LDS_LD + rt[mt] * 16 + q.lr];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bf[nt], acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            double *row = tile + (size_t)(rt[mt] * 16 + q.lk + 4 * v) * p.ld + c_off + q.lr;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) row[nt * 16] = acc[mt][nt][v];
+        }
+    if (cb >= p.nrb) return;  // candidate columns: no right-hand-side update
+    double *part = lds;  // [8][128]; only this workgroup's WCOLS columns are written and read
+    const double *zb = p.yz + (size_t)b * p.nrb * NB + (size_t)j * NB;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) y_partial<NT>(acc[mt], rt[mt], zb, part, c_off, q);
+    __syncthreads();
+    const int c0 = (tp - t * PARTS) * WCOLS;
+    if (tid < WCOLS) y_commit(part, p.yz + (size_t)b * p.nrb * NB + (size_t)cb * NB, c0 + tid);
 }
 
 // right-hand-side block := identity (N x N inside the padded candidate columns)
@@ -1279,6 +1351,12 @@ constexpr int64_t SPLITK_LAYOUT_MAX_WORK = BARK_SPLITK_LAYOUT_MAX_WORK;
 #ifndef BARK_PIPE_ALL_SIZES
 #define BARK_PIPE_ALL_SIZES 0
 #endif
+#ifndef BARK_SOLVE_NARROW
+#define BARK_SOLVE_NARROW 1
+#endif
+#ifndef BARK_SOLVE_NARROW_MAX_WGS
+#define BARK_SOLVE_NARROW_MAX_WGS 256
+#endif
 #ifndef BARK_PIPE_STREAMS
 #define BARK_PIPE_STREAMS 2
 #endif
@@ -1367,6 +1445,8 @@ int set_lds_limits() {
         if (e == hipSuccess) e = set(reinterpret_cast<const void *>(vtv_kernel), GEMM_LDS);
         if (e == hipSuccess) e = set(reinterpret_cast<const void *>(solve_kernel<0>), GEMM_LDS);
         if (e == hipSuccess) e = set(reinterpret_cast<const void *>(solve_kernel<1>), GEMM_LDS);
+        if (e == hipSuccess) e = set(reinterpret_cast<const void *>(solve_narrow_kernel<1>), GEMM_LDS);
+        if (e == hipSuccess) e = set(reinterpret_cast<const void *>(solve_narrow_kernel<2>), GEMM_LDS);
         status[dev] = (int)e;
     });
     if (status[dev] != 0)
@@ -1585,7 +1665,13 @@ struct Sweep {
         if (n_right > 0) {
             if (timed) solve_marks.push_back(ev.size());
             if ((r = mark_on(s))) return r;
-            hipLaunchKernelGGL(solve_kernel<0>, dim3(xcd_grid(n_right, bc)), dim3(THREADS), GEMM_LDS, s, p, j, n_right);
+            // few tiles (the critical path of lone matrices): share a tile's columns out over 4 or 2 workgroups
+            if (BARK_SOLVE_NARROW && (long)n_right * bc * 4 <= BARK_SOLVE_NARROW_MAX_WGS)
+                hipLaunchKernelGGL(solve_narrow_kernel<1>, dim3(xcd_grid(n_right * 4, bc)), dim3(THREADS), GEMM_LDS, s, p, j, n_right);
+            else if (BARK_SOLVE_NARROW && (long)n_right * bc * 2 <= BARK_SOLVE_NARROW_MAX_WGS)
+                hipLaunchKernelGGL(solve_narrow_kernel<2>, dim3(xcd_grid(n_right * 2, bc)), dim3(THREADS), GEMM_LDS, s, p, j, n_right);
+            else
+                hipLaunchKernelGGL(solve_kernel<0>, dim3(xcd_grid(n_right, bc)), dim3(THREADS), GEMM_LDS, s, p, j, n_right);
             BARK_LAUNCH_CHECK();
             if ((r = mark_on(s))) return r;
             // 18 of the 32 (k-tile, row-tile) products per wave are executed (zero k-tiles of W_j skipped)
