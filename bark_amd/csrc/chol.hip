@@ -1049,9 +1049,9 @@ __global__ __launch_bounds__(THREADS, 2) void solve_kernel(Mats p, int j, int n_
 // Each workgroup still stages the whole k-rows of T (L2-resident: the reduce kernel just wrote them).  Per column the
 // arithmetic and its order are those of solve_kernel: identical results.
 // ---------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, int DEF = 0>  // DEF == 1: the K = 256 product of solve_kernel<1> (dense block first, then W_j)
 __global__ __launch_bounds__(THREADS, 2) void solve_narrow_kernel(Mats p, int j, int n_right) {
-    constexpr int PARTS = 4 / NT, WCOLS = 32 * NT, nk = NB / BK;
+    constexpr int PARTS = 4 / NT, WCOLS = 32 * NT, nd = DEF * (NB / BK), nk = nd + NB / BK;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
     int b, tp;
@@ -1060,7 +1060,8 @@ __global__ __launch_bounds__(THREADS, 2) void solve_narrow_kernel(Mats p, int j,
     const int t = tp / PARTS, c_off = (tp - t * PARTS) * WCOLS + q.wc * 16 * NT;  // this wave's first column in the tile
     const int cb = j + 1 + t;
     double *tile = p.A + (size_t)b * p.bstride + (size_t)j * NB * p.ld + (size_t)cb * NB;
-    const double *Wb = p.W + (size_t)b * W_STRIDE + (size_t)NB * NB;
+    const double *Wb = p.W + (size_t)b * W_STRIDE + (size_t)(1 - DEF) * NB * NB;  // [-G_j ;] W_j
+    const double *Tp = tile - (size_t)DEF * NB * p.ld;                              // [U[j-1,i] ;] T[j,i]
     const int wr_u = __builtin_amdgcn_readfirstlane(q.wr);
     const int rt[4] = {wr_u ? 1 : 0, wr_u ? 2 : 3, wr_u ? 5 : 4, wr_u ? 6 : 7};
     f64x4 acc[4][NT];
@@ -1069,12 +1070,12 @@ __global__ __launch_bounds__(THREADS, 2) void solve_narrow_kernel(Mats p, int j,
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f64x4){0.0, 0.0, 0.0, 0.0};
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    stage_dma(Wb, NB, tile, p.ld, 0, lds, wave, lane);
+    stage_dma(Wb, NB, Tp, p.ld, 0, lds, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) stage_dma(Wb, NB, tile, p.ld, kt + 1, lds + ((kt + 1) & 1) * STAGE, wave, lane);
+        if (kt + 1 < nk) stage_dma(Wb, NB, Tp, p.ld, kt + 1, lds + ((kt + 1) & 1) * STAGE, wave, lane);
         const double *As = lds + (kt & 1) * STAGE;
         const double *Bs = As + BK * LDS_LD;
 #pragma unroll
@@ -1084,7 +1085,7 @@ __global__ __launch_bounds__(THREADS, 2) void solve_narrow_kernel(Mats p, int j,
             for (int nt = 0; nt < NT; ++nt) bf[nt] = Bs[(kk * 4 + q.lk) * LDS_LD + c_off + nt * 16 + q.lr];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                if (kt <= rt[mt]) {  // wave-uniform
+                if (kt < nd || kt - nd <= rt[mt]) {  // wave-uniform: dense block, then the triangular skip
                     const double a = As[(kk * 4 + q.lk) * LDS_LD + rt[mt] * 16 + q.lr];
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
@@ -1357,6 +1358,9 @@ constexpr int64_t SPLITK_LAYOUT_MAX_WORK = BARK_SPLITK_LAYOUT_MAX_WORK;
 #ifndef BARK_SOLVE_NARROW_MAX_WGS
 #define BARK_SOLVE_NARROW_MAX_WGS 256
 #endif
+#ifndef BARK_PIPE_NARROW_MAX_WGS
+#define BARK_PIPE_NARROW_MAX_WGS 256
+#endif
 #ifndef BARK_PIPE_STREAMS
 #define BARK_PIPE_STREAMS 2
 #endif
@@ -1447,6 +1451,8 @@ int set_lds_limits() {
         if (e == hipSuccess) e = set(reinterpret_cast<const void *>(solve_kernel<1>), GEMM_LDS);
         if (e == hipSuccess) e = set(reinterpret_cast<const void *>(solve_narrow_kernel<1>), GEMM_LDS);
         if (e == hipSuccess) e = set(reinterpret_cast<const void *>(solve_narrow_kernel<2>), GEMM_LDS);
+        if (e == hipSuccess) e = set(reinterpret_cast<const void *>(solve_narrow_kernel<1, 1>), GEMM_LDS);
+        if (e == hipSuccess) e = set(reinterpret_cast<const void *>(solve_narrow_kernel<2, 1>), GEMM_LDS);
         status[dev] = (int)e;
     });
     if (status[dev] != 0)
@@ -1752,10 +1758,21 @@ struct Sweep {
         if (n_right > 0) {
             if (timed) solve_marks.push_back(ev.size());
             if ((r = mark_on(main))) return r;
-            if (deferred)
-                hipLaunchKernelGGL(solve_kernel<1>, dim3(xcd_grid(n_right, bc)), dim3(THREADS), GEMM_LDS, main, p, j, n_right);
+            const long wgs = (long)n_right * bc;
+            const int parts = !BARK_SOLVE_NARROW ? 1 : wgs * 4 <= BARK_PIPE_NARROW_MAX_WGS ? 4 : wgs * 2 <= BARK_PIPE_NARROW_MAX_WGS ? 2 : 1;
+            const dim3 g(xcd_grid(n_right * parts, bc)), blk(THREADS);
+            if (deferred && parts == 4)
+                hipLaunchKernelGGL((solve_narrow_kernel<1, 1>), g, blk, GEMM_LDS, main, p, j, n_right);
+            else if (deferred && parts == 2)
+                hipLaunchKernelGGL((solve_narrow_kernel<2, 1>), g, blk, GEMM_LDS, main, p, j, n_right);
+            else if (deferred)
+                hipLaunchKernelGGL(solve_kernel<1>, g, blk, GEMM_LDS, main, p, j, n_right);
+            else if (parts == 4)
+                hipLaunchKernelGGL((solve_narrow_kernel<1, 0>), g, blk, GEMM_LDS, main, p, j, n_right);
+            else if (parts == 2)
+                hipLaunchKernelGGL((solve_narrow_kernel<2, 0>), g, blk, GEMM_LDS, main, p, j, n_right);
             else
-                hipLaunchKernelGGL(solve_kernel<0>, dim3(xcd_grid(n_right, bc)), dim3(THREADS), GEMM_LDS, main, p, j, n_right);
+                hipLaunchKernelGGL(solve_kernel<0>, g, blk, GEMM_LDS, main, p, j, n_right);
             BARK_LAUNCH_CHECK();
             if ((r = mark_on(main))) return r;
             solve_flops += ((deferred ? 32.0 : 0.0) + 18.0) / 32.0 * 2.0 * NB * NB * (double)NB * (double)n_right * (double)bc;
