@@ -1323,17 +1323,19 @@ constexpr long TAIL_MAX_WGS = BARK_TAIL_MAX_WGS;  // ragged_tail: largest last r
 #define BARK_SPLITK_LAYOUT_MAX_TILES 600
 #endif
 #ifndef BARK_SPLITK_LAYOUT_MAX_WORK
-#define BARK_SPLITK_LAYOUT_MAX_WORK 5600
+#define BARK_SPLITK_LAYOUT_MAX_WORK 3000
 #endif
 // Which chunks get the split-K layout (slab scratch reserved, A materialised, look-ahead schedule of Sweep::step) and
 // which the pipelined schedule (Sweep::step_pipelined, which splits K in its under-filled launches too).  The
 // look-ahead schedule has the shorter critical path per block step (diag + solve against a longer diag + a K = 256 solve),
 // the pipelined one keeps the chip full; so the split-K layout is for sweeps bound by their critical path: fewer than
-// MAX_WORK (matrices x block columns) x block rows.  Build-time tuning constants; split-K layout | pipelined, ms:
-//   N = 4096:  B = 4 3.76 | 3.94, B = 6 5.57 | 5.21, B = 8 5.00 | 4.84, B = 16 9.12 | 7.39, B = 32 16.1 | 13.1
-//   N = 8192:  B = 1 7.33 | 7.71, B = 2 9.39 | 9.16, B = 3 17.2 | 15.0, B = 8 31.5 | 25.2
-//   N = 16384: B = 1 27.9 | 27.1, B = 4 115 | 95        N = 2048: B = 8 1.62 | 1.84, B = 16 2.03 | 2.11, B = 32 3.07 | 2.82
-//   N = 1024:  B = 24 0.78 | 0.97, B = 64 1.16 | 1.19
+// MAX_WORK (matrices x block columns) x block rows.  Build-time tuning constants; split-K layout | pipelined, ms, with
+// the narrow solve kernels in both:
+//   N = 4096:  B = 2 2.81 | 3.12, B = 3 4.00 | 3.49, B = 4 3.55 | 3.49, B = 5 5.31 | 4.29, B = 8 4.89 | 4.57, B = 16 9.1 | 7.2
+//   N = 8192:  B = 1 6.80 | 6.65, B = 2 9.08 | 8.41     N = 5000: B = 2 4.00 | 4.10, B = 3 6.17 | 5.12
+//   N = 3000:  B = 4 2.28 | 2.40, B = 6 3.08 | 2.70     N = 2048: B = 8 1.47 | 1.54, B = 12 1.97 | 1.80, B = 16 1.93 | 1.87
+//   N = 1024:  B = 32 0.76 | 0.87, B = 40 0.87 | 0.87, B = 64 1.11 | 1.14
+// i.e. the crossover sits near 3000 for every N (it was 5600 before the narrow solves shortened the pipelined chain).
 // Below 8 block rows (no pipelining) the rule is the tile count alone.
 constexpr int SPLITK_LAYOUT_MAX_TILES = BARK_SPLITK_LAYOUT_MAX_TILES;
 constexpr int64_t SPLITK_LAYOUT_MAX_WORK = BARK_SPLITK_LAYOUT_MAX_WORK;

@@ -121,7 +121,7 @@ def test_sweep_is_hipgraph_capturable(env):
     torch.cuda.synchronize()
     assert bool((wl2.mll_d == eager2).all())
     # and the split-K look-ahead schedule (third stream: the bulk of step j+2 forks after solve(j) and joins two steps later)
-    wl3 = bench.Workload(4096, 8, 50, 4, seed_base=4096, rank_offset=0)  # split-K layout; (tiles x matrices) x block rows >= 600 from step 7 on
+    wl3 = bench.Workload(6900, 8, 50, 1, seed_base=6900, rank_offset=0)  # 54 block rows: still the split-K layout, look-ahead in the middle steps
     wl3.run()
     torch.cuda.synchronize()
     eager3 = wl3.mll_d.clone()

@@ -19,8 +19,9 @@ CASES = [
     # generated and materialised Gram, candidate columns, a shorter last chunk, and its plain-schedule neighbour B = 256
     (1100, 130, 50, 0, None), (1300, 200, 20, 0, 120), (2100, 70, 50, 0, None), (1000, 150, 25, 130, None),
     (1500, 100, 30, 200, None), (1100, 256, 50, 0, None),
-    # split-K layout whose late steps are bound by the look-ahead bulk (two bulk streams): few matrices, many candidate columns
-    (2100, 2, 50, 13200, None),
+    # split-K layout with look-ahead, its last step bound by the bulk (second bulk stream): one small matrix, many candidate
+    # columns — (16 + 171 block columns) x 16 block rows stays below the layout threshold
+    (2000, 1, 50, 21800, None),
 ]
 
 
