@@ -1339,36 +1339,20 @@ constexpr long TAIL_MAX_WGS = BARK_TAIL_MAX_WGS;  // ragged_tail: largest last r
 // Below 8 block rows (no pipelining) the rule is the tile count alone.
 constexpr int SPLITK_LAYOUT_MAX_TILES = BARK_SPLITK_LAYOUT_MAX_TILES;
 constexpr int64_t SPLITK_LAYOUT_MAX_WORK = BARK_SPLITK_LAYOUT_MAX_WORK;
-#ifndef BARK_DIAG_SHARE_BESIDE_BULK
-#define BARK_DIAG_SHARE_BESIDE_BULK 2
-#endif
-#ifndef BARK_LA_STREAMS
-#define BARK_LA_STREAMS 2
-#endif
-#ifndef BARK_PIPE_SPLIT
-#define BARK_PIPE_SPLIT 1
-#endif
+// Build-time tuning constants of the pipelined schedule (numbers only: every on/off alternative that was measured and
+// lost is gone from the sources, with its figures left in the comment next to the code that won).
 #ifndef BARK_PIPE_MIN_NRB
 #define BARK_PIPE_MIN_NRB 8
 #endif
-#ifndef BARK_PIPE_ALL_SIZES
-#define BARK_PIPE_ALL_SIZES 0
-#endif
-#ifndef BARK_SOLVE_NARROW
-#define BARK_SOLVE_NARROW 1
-#endif
+constexpr int PIPE_MIN_NRB = BARK_PIPE_MIN_NRB;  // fewer block rows: plain schedule (no difference measured at N = 512..896)
 #ifndef BARK_SOLVE_NARROW_MAX_WGS
 #define BARK_SOLVE_NARROW_MAX_WGS 256
 #endif
 #ifndef BARK_PIPE_NARROW_MAX_WGS
 #define BARK_PIPE_NARROW_MAX_WGS 256
 #endif
-#ifndef BARK_PIPE_STREAMS
-#define BARK_PIPE_STREAMS 2
-#endif
-#ifndef BARK_PIPELINE
-#define BARK_PIPELINE 1  // chunks outside the split-K layout use Sweep::step_pipelined (0: the plain schedule, for A/B runs)
-#endif
+// a solve of at most this many workgroups after sharing its tiles' columns out goes narrow (look-ahead / pipelined schedule)
+constexpr long SOLVE_NARROW_MAX_WGS = BARK_SOLVE_NARROW_MAX_WGS, PIPE_NARROW_MAX_WGS = BARK_PIPE_NARROW_MAX_WGS;
 
 struct Layout {
     int64_t npad, cpad, ncols, ld, W;
@@ -1401,7 +1385,7 @@ Layout make_layout(int64_t N, int64_t C, int64_t m, int64_t Bc) {
     L.off_slab = o;
     {
         const int64_t nrb = L.npad / NB, tiles = Bc * (L.ncols / NB);
-        L.splitk = nrb >= 4 && (nrb < BARK_PIPE_MIN_NRB ? tiles < SPLITK_LAYOUT_MAX_TILES : tiles * nrb < SPLITK_LAYOUT_MAX_WORK);
+        L.splitk = nrb >= 4 && (nrb < PIPE_MIN_NRB ? tiles < SPLITK_LAYOUT_MAX_TILES : tiles * nrb < SPLITK_LAYOUT_MAX_WORK);
     }
     // two slab sets (look-ahead: the bulk of step j+1 is accumulated while step j is reduced); a split step has fewer
     // than SPLITK_SLOTS / 2 tiles x matrices, S of at most SPLITK_SLOTS / that, plus one slab for the last block row
@@ -1520,12 +1504,7 @@ struct Sweep {
         // 200-300 us in the middle steps); there it asks for its 83 KiB and lands beside a single bulk workgroup.  (The
         // pipelined schedule's row launches retire workgroups continuously: there the whole-CU request stays the
         // better choice — one N = 16384 matrix 26.6 against 28.3 ms, N = 4096 x 8 4.87 against 5.34.)
-        bool exclusive = p.Bc <= DIAG_EXCLUSIVE_MAX_BC;
-#if BARK_DIAG_SHARE_BESIDE_BULK == 1
-        if (lookahead(j + 1) && la_slots(j + 1) == LA_SLOTS) exclusive = false;
-#elif BARK_DIAG_SHARE_BESIDE_BULK == 2
-        if (lookahead(j + 1)) exclusive = false;
-#endif
+        const bool exclusive = p.Bc <= DIAG_EXCLUSIVE_MAX_BC && !lookahead(j + 1);
         hipLaunchKernelGGL(diag_kernel, dim3((unsigned)p.Bc), dim3(THREADS), exclusive ? DIAG_LDS_EXCLUSIVE : DIAG_LDS, main, p, j, nkb, want_g);
         BARK_LAUNCH_CHECK();
         return mark_on(main);
@@ -1674,9 +1653,9 @@ struct Sweep {
             if (timed) solve_marks.push_back(ev.size());
             if ((r = mark_on(s))) return r;
             // few tiles (the critical path of lone matrices): share a tile's columns out over 4 or 2 workgroups
-            if (BARK_SOLVE_NARROW && (long)n_right * bc * 4 <= BARK_SOLVE_NARROW_MAX_WGS)
+            if ((long)n_right * bc * 4 <= SOLVE_NARROW_MAX_WGS)
                 hipLaunchKernelGGL(solve_narrow_kernel<1>, dim3(xcd_grid(n_right * 4, bc)), dim3(THREADS), GEMM_LDS, s, p, j, n_right);
-            else if (BARK_SOLVE_NARROW && (long)n_right * bc * 2 <= BARK_SOLVE_NARROW_MAX_WGS)
+            else if ((long)n_right * bc * 2 <= SOLVE_NARROW_MAX_WGS)
                 hipLaunchKernelGGL(solve_narrow_kernel<2>, dim3(xcd_grid(n_right * 2, bc)), dim3(THREADS), GEMM_LDS, s, p, j, n_right);
             else
                 hipLaunchKernelGGL(solve_kernel<0>, dim3(xcd_grid(n_right, bc)), dim3(THREADS), GEMM_LDS, s, p, j, n_right);
@@ -1715,7 +1694,7 @@ struct Sweep {
     bool has_bulk(int j) const { return j < nrb_steps && tiles_of(j) > 0 && (kdone(j) > 0 || fused); }
     int launch_bulk(int j) {  // everything enqueued on `main` so far precedes it
         if (!has_bulk(j)) return BARK_OK;
-        hipStream_t st = (BARK_PIPE_STREAMS > 1 && (j & 1)) ? la_stream : panel;
+        hipStream_t st = (j & 1) ? la_stream : panel;  // one bulk stream only: B = 256 at N = 4096 94 -> 100 ms
         int r;
         BARK_HIP_CHECK(hipEventRecord(res->events[6 * j + 3], main));
         BARK_HIP_CHECK(hipStreamWaitEvent(st, res->events[6 * j + 3], 0));
@@ -1726,7 +1705,7 @@ struct Sweep {
         // the bulk streams).  N = 4096, B = 32: the last 8 steps took 3.5 of 13.9 ms.
         const int k = kdone(j), nt = tiles_of(j);
         int S = 1;
-        if (BARK_PIPE_SPLIT && k >= 2 && nt * p.Bc < SPLITK_SLOTS / 2) {
+        if (k >= 2 && nt * p.Bc < SPLITK_SLOTS / 2) {
             S = (2 * LA_SLOTS + nt * p.Bc) / (2 * nt * p.Bc);
             if (S > k) S = k;
             if (S > SPLITK_MAX) S = SPLITK_MAX;
@@ -1761,7 +1740,7 @@ struct Sweep {
             if (timed) solve_marks.push_back(ev.size());
             if ((r = mark_on(main))) return r;
             const long wgs = (long)n_right * bc;
-            const int parts = !BARK_SOLVE_NARROW ? 1 : wgs * 4 <= BARK_PIPE_NARROW_MAX_WGS ? 4 : wgs * 2 <= BARK_PIPE_NARROW_MAX_WGS ? 2 : 1;
+            const int parts = wgs * 4 <= PIPE_NARROW_MAX_WGS ? 4 : wgs * 2 <= PIPE_NARROW_MAX_WGS ? 2 : 1;
             const dim3 g(xcd_grid(n_right * parts, bc)), blk(THREADS);
             if (deferred && parts == 4)
                 hipLaunchKernelGGL((solve_narrow_kernel<1, 1>), g, blk, GEMM_LDS, main, p, j, n_right);
@@ -1877,7 +1856,7 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
     sw.nrb = nrb;
     sw.nrb_steps = nrb;
     sw.la_stream = ctx->helper2;
-    sw.la_stream2 = BARK_LA_STREAMS > 1 ? ctx->helper3 : ctx->helper2;
+    sw.la_stream2 = ctx->helper3;
     sw.ncb = ncb;
     sw.fused = fused;
     sw.splitk = splitk;
@@ -1887,7 +1866,7 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
     // N = 4096 (93.6 | 93.7 ms at B = 256), the plain one wins beyond (B = 512: 186.6 | 188.6; N = 8192, B = 256:
     // 696 | 711) and the pipelined one up to 16 block rows (N = 2048: 14.1 | 13.8, N = 1024: 2.65 | 2.56).  Fewer than 8
     // block rows: no difference measured (N = 512..896), plain.
-    const bool pipeline_ok = BARK_PIPELINE != 0 && !splitk && nrb >= BARK_PIPE_MIN_NRB;  // decided per chunk below
+    const bool pipeline_ok = !splitk && nrb >= PIPE_MIN_NRB;  // decided per chunk below
     sw.rep = rep;
     sw.slabs = slabs;
     sw.timed = timing != nullptr;
@@ -1974,7 +1953,7 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
     if ((rc = sw.mark_on(caller))) return rc;
     for (int64_t c0 = 0; c0 < B; c0 += Bc) {  // chunks of Bc resident matrices, one after the other
         const int64_t bc = (B - c0 < Bc) ? (B - c0) : Bc;
-        sw.pipelined = pipeline_ok && (BARK_PIPE_ALL_SIZES != 0 || (bc % 256) != 0 || nrb <= 16);
+        sw.pipelined = pipeline_ok && ((bc % 256) != 0 || nrb <= 16);
         if ((rc = prologue(c0, bc))) return rc;
         for (int j = 0; j < nrb; ++j)
             if ((rc = sw.step(j))) return rc;
@@ -2077,7 +2056,7 @@ static int leafspace_run(bark_ctx *ctx, const void *packed, const bark_pack_info
     sw.nrb = nrb;
     sw.nrb_steps = nrb;
     sw.la_stream = ctx->helper2;
-    sw.la_stream2 = BARK_LA_STREAMS > 1 ? ctx->helper3 : ctx->helper2;
+    sw.la_stream2 = ctx->helper3;
     sw.ncb = ncb;
     sw.fused = false;
     sw.splitk = g.L.splitk;
@@ -2114,7 +2093,7 @@ static int leafspace_run(bark_ctx *ctx, const void *packed, const bark_pack_info
         const char *packed_c = static_cast<const char *>(packed) + (size_t)c0 * m * info->stride * 16;
         p.info = info_out + c0;
         p.Bc = (int)bc;
-        sw.pipelined = BARK_PIPELINE != 0 && !g.L.splitk && nrb >= BARK_PIPE_MIN_NRB && (BARK_PIPE_ALL_SIZES != 0 || (bc % 256) != 0 || nrb <= 16);  // as the dense entry
+        sw.pipelined = !g.L.splitk && nrb >= PIPE_MIN_NRB && ((bc % 256) != 0 || nrb <= 16);  // as the dense entry
         if ((rc = walk_one_hot(packed_c, &sub, X, N, d, (int)g.W, codes, ctx->fault, caller))) return rc;
         rc = leafspace_prepare(codes, (int)g.W, (int)g.npad, planes, (int)g.R, (int)g.Rpad, noise + c0,
                                use_scale ? scale + c0 : nullptr, (int)m, (int)bc, p.A, p.ld, p.bstride, y, (int)N, p.yz,
