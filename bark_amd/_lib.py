@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -169,32 +170,54 @@ def to_device(a, dtype=None):
 _tls = threading.local()
 
 
+def _destroy_ctx(handle_value: int, device: int):
+    """Finalizer of a _Ctx: drain the device (the context's helper streams may still run) and free everything the
+    context owns.  Runs when the owning thread's locals are collected, at release_ctx(), or at interpreter exit."""
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.synchronize(device)
+        lib().bark_ctx_destroy(vp(handle_value))
+    except Exception:  # interpreter teardown: the HIP runtime may already be gone
+        pass
+
+
+class _Ctx:
+    """Owner of one bark_ctx handle.  threading.local drops a dead thread's dict, which drops this object, whose
+    finalizer destroys the context — a thread that exits without release_ctx() no longer leaks its helper streams,
+    events, pinned page and grow-only scratch (tens of GB after a c3-sized call)."""
+
+    __slots__ = ("handle", "device", "_fin", "__weakref__")
+
+    def __init__(self, device: int):
+        h = vp()
+        check(lib().bark_ctx_create(device, ctypes.byref(h)))
+        self.handle, self.device = h, device
+        self._fin = weakref.finalize(self, _destroy_ctx, h.value, device)
+
+    def close(self):
+        self._fin()
+
+
 def ctx():
     """The calling thread's bark_ctx for the current device (created on first use).  Host threads never share a
     context, so concurrent callers on their own streams share no mutable library state."""
-    import torch
-
     dev = torch_device().index
     handles = getattr(_tls, "handles", None)
     if handles is None:
         handles = _tls.handles = {}
-    h = handles.get(dev)
-    if h is None:
-        h = vp()
-        check(lib().bark_ctx_create(dev, ctypes.byref(h)))
-        handles[dev] = h
-    return h
+    c = handles.get(dev)
+    if c is None:
+        c = handles[dev] = _Ctx(dev)
+    return c.handle
 
 
 def release_ctx():
     """Destroy the calling thread's contexts (frees their scratch buffers); they are re-created on demand."""
-    import torch
-
     handles = getattr(_tls, "handles", None) or {}
-    if handles and torch.cuda.is_available():
-        torch.cuda.synchronize()
-    for h in handles.values():
-        lib().bark_ctx_destroy(h)
+    for c in list(handles.values()):
+        c.close()
     handles.clear()
     cache = getattr(_tls, "packed", None)
     if cache is not None:
@@ -202,7 +225,9 @@ def release_ctx():
 
 
 class Scratch:
-    """View of the context's grow-only device scratch (valid until a larger request or release_ctx)."""
+    """View of the context's grow-only device scratch.  INVALIDATED by the next `workspace()` call of this thread that
+    asks for more bytes (the old buffer is freed after a device synchronisation) and by release_ctx(): fetch it
+    immediately before the call that uses it and do not keep it across calls."""
 
     def __init__(self, ptr_value: int, nbytes: int):
         self._ptr, self._n = ptr_value, nbytes
@@ -215,15 +240,25 @@ class Scratch:
 
 
 def workspace(nbytes: int) -> Scratch:
+    """The calling thread's scratch, grown to at least `nbytes`.  The buffer is a raw hipMalloc outside torch's
+    caching allocator, so a failed growth is retried once after handing torch's cached-but-free blocks back to the
+    driver; a second failure raises MemoryError."""
     out = vp()
-    check(lib().bark_ctx_workspace(ctx(), int(nbytes), ctypes.byref(out)))
+    rc = lib().bark_ctx_workspace(ctx(), int(nbytes), ctypes.byref(out))
+    if rc == BARK_ERR_WORKSPACE:
+        import torch
+
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        rc = lib().bark_ctx_workspace(ctx(), int(nbytes), ctypes.byref(out))
+    check(rc)
     assert out.value % 256 == 0
     return Scratch(out.value, int(lib().bark_ctx_workspace_bytes(ctx())))
 
 
 def workspace_bytes() -> int:
     handles = getattr(_tls, "handles", None) or {}
-    return sum(int(lib().bark_ctx_workspace_bytes(h)) for h in handles.values())
+    return sum(int(lib().bark_ctx_workspace_bytes(c.handle)) for c in handles.values())
 
 
 def release_workspace():

@@ -569,15 +569,19 @@ void launch_rewrite(hipStream_t stream, const double *K, int N, int r, const dou
 // Metropolis decision of one tree proposal per chain on the device (bark_sampler.py:256-264):
 //   log_alpha = log_q_prior + (new_mll - cur_mll),  new_mll - cur_mll = 0.5 (dquad - dlogdet)   (scalars = {dquad, dlogdet})
 //   accept iff log(u) <= min(log_alpha, 0);  on accept the chain's running y'K^-1 y and log|K| move with it.
-// accept_out: 1 / 0, or -1 when the r x r system was singular (the reference raises LinAlgError there).
+// accept_out: 1 / 0, or -1 when the r x r system was singular (the reference raises LinAlgError there).  A chain that
+// met a singular system stays at -1 for the rest of the sweep (accept_prev = the previous step's flags, null for the
+// first): its K_inv is not rewritten again, so K_inv, quad and logdet of that chain still belong together — the state
+// after its last accepted step — when the host raises.
 __global__ void decide_kernel(const double *__restrict__ scalars, const double *__restrict__ log_q_prior,
                               const double *__restrict__ log_u, const int *__restrict__ flags, size_t flag_stride_ints,
-                              int nc, double *__restrict__ state, int32_t *__restrict__ accept_out) {
+                              int nc, double *__restrict__ state, const int32_t *__restrict__ accept_prev,
+                              int32_t *__restrict__ accept_out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nc) return;
     const double dquad = scalars[2 * b], dlogdet = scalars[2 * b + 1];
     int acc;
-    if (flags[(size_t)b * flag_stride_ints] != 0) {
+    if (flags[(size_t)b * flag_stride_ints] != 0 || (accept_prev && accept_prev[b] < 0)) {
         acc = -1;
     } else {
         const double log_alpha = log_q_prior[b] + 0.5 * (dquad - dlogdet);
@@ -928,7 +932,7 @@ int bark_tree_sweep_chains_hip(bark_ctx *ctx, double *K_inv, int64_t N, int64_t 
         const LowRankWs w = lowrank_ws(ws, N, r);
         int32_t *acc = accept_out + t * nc;
         hipLaunchKernelGGL(decide_kernel, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, caller, scalars, log_q_prior + t * nc,
-                           log_u + t * nc, w.flag, stride / sizeof(int), (int)nc, state, acc);
+                           log_u + t * nc, w.flag, stride / sizeof(int), (int)nc, state, t > 0 ? acc - nc : nullptr, acc);
         BARK_LAUNCH_CHECK();
         launch_rewrite(caller, K_inv, (int)N, (int)r, w.Y, w.inv, w.M, w.Y, K_inv, ChainInts{}, (int)nc, ch, acc);
         BARK_LAUNCH_CHECK();

@@ -446,9 +446,13 @@ class ChainBatch:
                                                   _lib.stream_ptr()))
         acc = accept.cpu().numpy()  # the one synchronisation of the sweep
         st = state.cpu().numpy()
+        # the device has already rewritten K_inv for every accepted step: take the running quad / logdet that belong to
+        # it BEFORE raising, so a caller that catches the error keeps a consistent batch (a singular chain is latched
+        # at -1 by decide_kernel and stays at the state after its last accepted step)
+        self.quad, self.logdet = st[:, 0].copy(), st[:, 1].copy()
+        self._pending = None
+        self.last_accept = acc.T.copy()
         _raise_on_categorical_fault(ft)
         if (acc < 0).any():
             raise np.linalg.LinAlgError("Singular matrix in a tree-swap update")
-        self.quad, self.logdet = st[:, 0].copy(), st[:, 1].copy()
-        self._pending = None
         return (acc.T > 0)

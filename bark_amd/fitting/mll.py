@@ -42,8 +42,9 @@ def _fit_chunk(B: int, need, budget_bytes: int | None = None) -> int:
     free device memory (counting the cached workspace as free), or $BARK_WORKSPACE_GB."""
     import torch
 
-    if budget_bytes is None and need(B) <= (256 << 20):
-        return int(B)  # small enough not to ask the driver (a latency-sensitive caller may be in a sampler loop)
+    if budget_bytes is None and not os.environ.get("BARK_WORKSPACE_GB") and need(B) <= (256 << 20):
+        return int(B)  # small enough not to ask the driver (a latency-sensitive caller may be in a sampler loop);
+        # an explicit budget (argument or $BARK_WORKSPACE_GB) is always honoured
     if budget_bytes is None:
         env = os.environ.get("BARK_WORKSPACE_GB")
         if env:

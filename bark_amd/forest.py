@@ -137,27 +137,45 @@ class PackedForest:
         return ctypes.byref(self.info)
 
 
-_PACK_CACHE_MAX_BYTES = 1 << 18  # only small inputs (a tree pair, one forest): hashing 33 MB costs more than packing it
+_PACK_CACHE_MAX_BYTES = 1 << 18  # small inputs (a tree pair, one forest) are keyed by their bytes
 _PACK_CACHE_ENTRIES = 64
+_PACK_CACHE_BIG_ENTRIES = 4       # sampler-sized batches (33 MB of records at c3) are keyed by a 128-bit xxh3 digest
+
+try:  # ~1 ms per 33 MB against 4-7 ms of validation + compaction + upload
+    from xxhash import xxh3_128_digest as _digest
+except ImportError:  # pragma: no cover - xxhash ships with the image; without it big inputs are simply re-packed
+    _digest = None
+
+pack_cache_stats = {"hits": 0, "misses": 0}  # process-wide counters (informational: bench / fitting-loop harness)
 
 
 def packed_forest(nodes3: np.ndarray, ft: np.ndarray) -> PackedForest:
     """PackedForest of `nodes3`, reusing the validated + uploaded copy when this thread packed the same bytes before
-    (the sampler evaluates one forest several times: proposal, rebuild on accept, posterior)."""
-    if nodes3.nbytes > _PACK_CACHE_MAX_BYTES:
+    (the sampler evaluates one forest several times: proposal, rebuild on accept, posterior; a fitting loop calls
+    TreeAgreementKernel.forward with one forest hundreds of times).  The key is the CONTENT of the records — callers
+    mutate forests in place (bark_sampler.py:148,264), so identity of the array proves nothing."""
+    big = nodes3.nbytes > _PACK_CACHE_MAX_BYTES
+    if big and _digest is None:
+        pack_cache_stats["misses"] += 1
         return PackedForest(nodes3, ft)
     cache = getattr(_lib._tls, "packed", None)
     if cache is None:
         from collections import OrderedDict
 
         cache = _lib._tls.packed = OrderedDict()
-    key = (nodes3.shape, nodes3.tobytes(), ft.tobytes(), _lib.torch_device().index)
+    content = _digest(nodes3.data) if big else nodes3.tobytes()
+    key = (big, nodes3.shape, content, ft.tobytes(), _lib.torch_device().index)
     pf = cache.get(key)
     if pf is None:
+        pack_cache_stats["misses"] += 1
         pf = cache[key] = PackedForest(nodes3, ft)
+        if big:  # keep only a few device copies of sampler-sized batches
+            for k in [k for k in cache if k[0]][:-_PACK_CACHE_BIG_ENTRIES]:
+                del cache[k]
         if len(cache) > _PACK_CACHE_ENTRIES:
             cache.popitem(last=False)
     else:
+        pack_cache_stats["hits"] += 1
         cache.move_to_end(key)
     return pf
 

@@ -59,11 +59,16 @@ def forest_predict(model, data, candidates, domain, diag: bool = True, method: s
 def mixture_of_gaussians_as_normal(mu, var):
     """tree_gps.py:116-131: moments of the equal-weight mixture over forest samples.
     (B x C elementwise host arithmetic, as in the reference; works on numpy or torch.)"""
-    if _is_torch(mu) and mu.is_cuda:
-        from ..distributed import reduce_mixture
-
-        return reduce_mixture(mu, var, int(mu.shape[0]), group=False)
     if _is_torch(mu):
+        import torch
+
+        # the HIP reduction reads raw contiguous (B, C) float64 pairs; anything else — float32, a full (B, C, C)
+        # covariance from diag=False, broadcasting shapes — takes the reference's formula in torch, by dtype and shape
+        if (mu.is_cuda and _is_torch(var) and var.is_cuda and mu.dtype == torch.float64 and var.dtype == torch.float64
+                and mu.ndim == 2 and var.shape == mu.shape):
+            from ..distributed import reduce_mixture
+
+            return reduce_mixture(mu, var, int(mu.shape[0]), group=False)
         mu_y = mu.mean(dim=0)
         var_y = (var + mu**2).mean(dim=0) - mu_y**2
         return mu_y, var_y

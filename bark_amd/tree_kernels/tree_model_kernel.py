@@ -8,7 +8,8 @@ Gram matrix as a torch tensor, or a vector of ones for `diag=True` (a point alwa
 Differences from the reference, all additive:
   * the Gram matrix comes from the HIP kernels (`bark_amd.forest.forest_gram_matrix`);
   * CUDA inputs are consumed and returned on the device — no `.numpy()` round trip inside botorch's
-    fitting loop (SURVEY §8f-4); CPU tensors are accepted too and give CPU tensors back;
+    fitting loop, `diag=True` included (float64 ones on x1's device); CPU tensors are accepted too and
+    give CPU tensors back (`diag=True`: the reference's `torch.ones(N)`);
   * gpytorch is optional (it is absent from the build image): when importable the class derives from
     `gpytorch.kernels.Kernel`, otherwise from a bare stand-in, with the same `forward`.
 """
@@ -59,5 +60,7 @@ class TreeAgreementKernel(_kernel_base()):
     def forward(self, x1: torch.Tensor, x2: torch.Tensor, diag: bool = False, **params):
         del params  # accepted for gpytorch's calling convention, unused (as in the reference)
         if diag:  # K(x, x) = 1: every tree puts a point in the same leaf as itself
-            return torch.ones(x1.shape[0])
+            if x1.is_cuda:  # device inputs get a device result in the Gram's dtype (no host round trip in a fitting loop)
+                return torch.ones(x1.shape[0], dtype=torch.float64, device=x1.device)
+            return torch.ones(x1.shape[0])  # CPU inputs: the reference's literal `torch.ones(x1.shape[0])`
         return self._gram(x1, x2)

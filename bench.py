@@ -61,6 +61,10 @@ def parse(argv=None):
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary per-config measurements")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU-only check of the launcher / rendezvous / gather / timing protocol (gloo, no GPU work)")
+    ap.add_argument("--require-rccl", action=argparse.BooleanOptionalAction, default=None,
+                    help="with --gpus > 1 and the nccl backend: an RCCL init / probe failure ends the run with a non-zero exit "
+                         "(default).  --no-require-rccl lets the 8-byte-per-sample MLL gather fall back to gloo instead; "
+                         "the JSON then says so (collective_backend != collective_backend_requested)")
     return ap.parse_args(argv)
 
 
@@ -305,34 +309,97 @@ def timed_region(wl, steps, warmup, world, dist, gather):
     return elapsed, call_ms, out
 
 
+def require_rccl(args, world, requested) -> bool:
+    """--require-rccl defaults to ON whenever there is an RCCL leg at all (more than one rank, nccl requested)."""
+    if world <= 1 or requested != "nccl":
+        return False
+    return True if args.require_rccl is None else bool(args.require_rccl)
+
+
+def init_collective(world, rank, dev_index, requested, must_be_rccl):
+    """Process group for the one exchange of the path (the MLL gather) -> (backend in use, rccl_ranks_seen).
+    `nccl` IS RCCL on ROCm; one tiny all-reduce proves the communicator before any timed region, and its value — the
+    number of ranks RCCL actually saw — goes into the JSON.  If RCCL cannot be brought up: with `must_be_rccl` the
+    worker exits non-zero (the launcher then ends every rank); without it the gather falls back to gloo in the SAME
+    process (no new process image), which changes nothing measurable for 8 bytes per sample but is stated in the JSON."""
+    if world <= 1:
+        return None, None
+    import datetime
+
+    import torch
+    import torch.distributed as dist
+
+    kw = dict(rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+    if requested != "nccl":
+        dist.init_process_group(requested, **kw)
+        return requested, None
+    try:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), **kw)
+        probe = torch.ones(1, device=torch.device("cuda", dev_index))
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        seen = int(probe.item())
+        if seen != world:
+            raise RuntimeError(f"RCCL all-reduce probe saw {seen} ranks, expected {world}")
+        return "nccl", seen
+    except Exception as exc:  # every rank sees the same failure
+        if must_be_rccl:
+            print(f"[bench rank {rank}] RCCL unavailable ({exc!r}) and --require-rccl is in force: giving up "
+                  "(pass --no-require-rccl to let the MLL gather use gloo)", file=sys.stderr, flush=True)
+            raise SystemExit(3)
+        print(f"[bench rank {rank}] RCCL unavailable ({exc!r}); --no-require-rccl: falling back to gloo for the MLL gather",
+              file=sys.stderr, flush=True)
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
+        os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17)
+        dist.init_process_group("gloo", **kw)
+        return "gloo", None
+
+
 # ---------------------------------------------------------------------------------------------
 # worker
 # ---------------------------------------------------------------------------------------------
 def selftest_worker(args, world, rank):
-    """Launcher / rendezvous / gather / timing protocol on CPU (gloo): what a worker does around the GPU work."""
+    """Launcher / rendezvous / collective set-up (incl. the RCCL-unavailable branch: BARK_BENCH_BACKEND=nccl on a box
+    without GPUs) / gather / timing protocol on CPU: everything a worker does around the GPU work, for the weak region
+    and — in weak mode with more than one rank — the c4 (512 samples, strong) region."""
     import torch
     import torch.distributed as dist
 
     from bark_amd.distributed import gather_mll, shard_range
 
-    if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+    requested = os.environ.get("BARK_BENCH_BACKEND", "gloo")
+    backend, seen = init_collective(world, rank, 0, requested, require_rccl(args, world, requested))
+
+    def region(total, lo, hi):
+        local = torch.arange(lo, hi, dtype=torch.float64)
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        full = gather_mll(local, total) if world > 1 else local
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return bool((full == torch.arange(total, dtype=torch.float64)).all()), elapsed
+
     total = args.total or args.batch * world
     lo, hi = shard_range(total, rank, world) if args.total else (rank * args.batch, (rank + 1) * args.batch)
-    local = torch.arange(lo, hi, dtype=torch.float64)
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    full = gather_mll(local, total) if world > 1 else local
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ok = bool((full == torch.arange(total, dtype=torch.float64)).all())
+    ok, _ = region(total, lo, hi)
+    c4 = None
+    if world > 1 and not args.total:  # the second timed region of a weak-scaling run
+        l4, h4 = shard_range(512, rank, world)
+        ok4, _ = region(512, l4, h4)
+        c4 = {"total": 512, "local": h4 - l4, "gather_ok": ok4, "scaling": "strong"}
+        ok = ok and ok4
     if rank == 0:
         print(json.dumps({"selftest": "launcher", "n_gpus": world, "ranks_reached": world, "gather_ok": ok,
                           "total": total, "local": hi - lo, "scaling": "strong" if args.total else "weak",
+                          "collective_backend_requested": requested if world > 1 else None,
+                          "collective_backend": backend, "rccl_ranks_seen": seen, "c4_strong": c4,
                           "launched_by": "bench.py" if os.environ.get("BARK_BENCH_WORKER") else "external"}), flush=True)
     if world > 1:
         dist.barrier()
@@ -361,29 +428,8 @@ def worker(args) -> int:
         raise SystemExit(f"--gpus {world} but only {ndev} devices (set BARK_BENCH_BACKEND=gloo to share a GPU in a dry run)")
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
-    if world > 1:
-        import datetime
-
-        kw = dict(rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
-        if backend == "nccl":
-            try:  # RCCL over xGMI; one tiny collective proves the communicator before the timed region
-                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), **kw)
-                probe = torch.ones(1, device=torch.device("cuda", dev_index))
-                dist.all_reduce(probe)
-                torch.cuda.synchronize()
-                assert int(probe.item()) == world
-            except Exception as exc:  # an unusable RCCL setup must not cost the scaling measurement: the exchange is 8 B
-                # per sample, so host staging over gloo changes nothing measurable.  Every rank sees the same failure.
-                print(f"[bench rank {rank}] RCCL unavailable ({exc!r}); falling back to gloo for the MLL gather", file=sys.stderr)
-                try:
-                    dist.destroy_process_group()
-                except Exception:
-                    pass
-                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17)
-                backend = "gloo"
-                dist.init_process_group("gloo", **kw)
-        else:
-            dist.init_process_group(backend, **kw)
+    requested = backend
+    backend, rccl_ranks_seen = init_collective(world, rank, dev_index, requested, require_rccl(args, world, requested))
 
     from bark_amd import _lib
     from bark_amd.distributed import gather_mll, shard_range
@@ -467,7 +513,9 @@ def worker(args) -> int:
                         ("c3: N=%d d=%d m=%d, %d prior forest samples per GPU (BASELINE configs[2]; sharding of "
                          "configs[3])" % (N, d, m, B)) + ", noise U[0.05,0.15), mcmc_record_mll convention",
             "N": N, "d": d, "trees": m, "forests_per_gpu": B, "forests_total": total, "chunk": wl.Bc,
-            "parallelism": "samples/%d" % world, "collective_backend": (backend if world > 1 else None), "launched_by": "bench.py" if os.environ.get("BARK_BENCH_WORKER") else "external",
+            "parallelism": "samples/%d" % world, "collective_backend": backend,
+            "collective_backend_requested": (requested if world > 1 else None), "rccl_ranks_seen": rccl_ranks_seen,
+            "launched_by": "bench.py" if os.environ.get("BARK_BENCH_WORKER") else "external",
             "timed_path": "production (timing=NULL, no host sync inside the library)",
         },
         "roofline": {
@@ -496,6 +544,161 @@ def worker(args) -> int:
         extras(args, wl, result, mll_host)
     print(json.dumps(result), flush=True)
     return 0
+
+
+def numpy_api_probe(wl, reps=3):
+    """The same c3 workload through the drop-in numpy API (bark_amd.fitting.batched_mll): host packing of the 26-byte
+    records (or the content-hash cache hit), H2D of the packed forest / X / y / noise, the sweep, D2H of the (B,) result.
+    PCIe-inclusive; never `value`."""
+    import numpy as np
+
+    import bark_amd.fitting as fit
+    from bark_amd import forest as bforest
+
+    def call(F):
+        t = time.perf_counter()
+        out = fit.batched_mll(F, wl.noise, None, wl.X, wl.y, wl.ft, include_scale=False, include_2pi=True, chunk=wl.Bc)
+        return time.perf_counter() - t, out
+
+    call(wl.forests)  # warm: workspace growth, first-use costs
+    cold = []
+    for i in range(reps):  # a changed batch every call (one record flipped back and forth): nothing to reuse
+        F = wl.forests.copy()
+        F[i, 0, 99]["depth"] = 7 + i  # an inactive, unreachable slot: same forests, different bytes
+        cold.append(call(F)[0])
+    h0 = dict(bforest.pack_cache_stats)
+    warm = [call(wl.forests)[0] for _ in range(reps)]
+    h1 = dict(bforest.pack_cache_stats)
+    _, out = call(wl.forests)
+    assert np.array_equal(out, wl.mll_d.cpu().numpy())
+    B = wl.B
+    return {"workload": "c3 through bark_amd.fitting.batched_mll on numpy inputs (pack + H2D + sweep + D2H)",
+            "ms_new_forests": 1e3 * sorted(cold)[len(cold) // 2], "evals_per_s_new_forests": B / sorted(cold)[len(cold) // 2],
+            "ms_same_forests_again": 1e3 * sorted(warm)[len(warm) // 2],
+            "evals_per_s_same_forests_again": B / sorted(warm)[len(warm) // 2],
+            "pack_cache_hits_in_repeat_calls": h1["hits"] - h0["hits"], "pack_cache_misses_in_repeat_calls": h1["misses"] - h0["misses"]}
+
+
+def sampler_step_probe(args, wl):
+    """SURVEY §8f-1 on record: one step of `_step_bark_sampler` (bark_sampler.py:217-284) at N = 4096, m = 50 — a sweep of
+    50 tree proposals decided on the device (ChainBatch.sweep_trees) + the noise/scale proposal (leaf-space MLL) + the
+    rebuild of the resident inverse on accept — for 1 and 4 chains; beside it the CPU oracle's Woodbury chain for the
+    same proposals (bounded sample).  Wall time includes the host side of the step (packing the tree pairs)."""
+    import numpy as np
+    import torch
+
+    import bark_amd.fitting as fit
+    from bark_amd import synthetic
+
+    N, m = wl.N, wl.m
+    X, y, ft = wl.X, wl.y, wl.ft
+    bounds = np.tile(np.array([[0.0, 1.0]]), (wl.d, 1))
+    Xd = wl.Xd
+    out = {"workload": "N=%d m=%d: 50 tree proposals (device-side Metropolis) + noise/scale proposal + rebuild" % (N, m)}
+    rng = np.random.default_rng(5)
+    for nc in (1, 4):
+        cur = synthetic.sample_prior_forests(nc, m, bounds, ft, seed=7000)
+        prop = synthetic.sample_prior_forests(nc, m, bounds, ft, seed=8000)
+        noise, scale = np.full(nc, 0.1), np.ones(nc)
+        log_q, log_u = rng.normal(0.0, 0.5, size=(nc, m)), np.log(rng.uniform(size=(nc, m)))
+        cb = fit.ChainBatch.from_forests(cur, noise, scale, Xd, y, ft)
+        cb.sweep_trees(cur, prop, log_q, log_u, Xd, ft, scale, m)  # warm-up (workspaces, packer)
+        torch.cuda.synchronize()
+        sweeps = []
+        for _ in range(3):
+            cb = fit.ChainBatch.from_forests(cur, noise, scale, Xd, y, ft)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            mask = cb.sweep_trees(cur, prop, log_q, log_u, Xd, ft, scale, m)
+            e1.record()
+            torch.cuda.synchronize()
+            sweeps.append((time.perf_counter() - t0, e0.elapsed_time(e1)))
+        wall, dev = sorted(sweeps)[1]
+        final = cur.copy()
+        final[mask] = prop[mask]
+        # noise/scale half: proposal MLL in leaf space, rebuild of the resident inverses on accept
+        def timed(fn, reps=5):
+            fn()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / reps
+
+        ns_eval = timed(lambda: fit.batched_mll(final, noise * 1.1, scale * 0.9, Xd, y, ft, include_scale=True,
+                                                include_2pi=False, method="leafspace"))
+        rebuild = timed(lambda: fit.batched_kernel_inverse(final, noise * 1.1, scale * 0.9, Xd, y, ft, no_null=False,
+                                                           return_device=True, method="leafspace"), reps=3)
+        dense_rebuild = timed(lambda: fit.batched_kernel_inverse(final, noise * 1.1, scale * 0.9, Xd, y, ft, no_null=False,
+                                                                 return_device=True), reps=2)
+        out["chains_%d" % nc] = {
+            "tree_sweep_wall_ms": 1e3 * wall, "tree_sweep_device_ms": dev, "ms_per_tree_proposal_per_chain": 1e3 * wall / (m * nc),
+            "accepted": int(mask.sum()), "noise_scale_proposal_ms": 1e3 * ns_eval, "rebuild_on_accept_ms_leafspace": 1e3 * rebuild,
+            "rebuild_on_accept_ms_dense": 1e3 * dense_rebuild,
+            "step_ms_if_noise_scale_accepted": 1e3 * (wall + ns_eval + rebuild),
+            "step_ms_if_noise_scale_rejected": 1e3 * (wall + ns_eval)}
+        if nc == 1 and args.cpu_sample > 0:  # the oracle's restated chain (quick_inverse.py:13-38) on the same proposals
+            from oracle import oracle as orc
+
+            K = orc.forest_gram_matrix(cur[0], X, X, ft)
+            K[np.diag_indices(N)] += 1e-6 + 0.1
+            K_inv = np.linalg.inv(K)
+            logdet = np.linalg.slogdet(K)[1]
+            s_sqrtm = np.sqrt(1.0 / m)
+            n_cpu = 3
+            t = time.perf_counter()
+            for ti in range(n_cpu):
+                U_old = s_sqrtm * orc.get_leaf_vectors(cur[0, ti], X, ft)
+                U_new = s_sqrtm * orc.get_leaf_vectors(prop[0, ti], X, ft)
+                K1 = orc.low_rank_inv_update(K_inv, U_old, subtract=True)
+                d1 = orc.low_rank_det_update(K_inv, U_old, logdet, subtract=True)
+                K2 = orc.low_rank_inv_update(K1, U_new)
+                d2 = orc.low_rank_det_update(K1, U_new, d1)
+                orc.mll(K2, d2, y)
+            cpu = (time.perf_counter() - t) / n_cpu
+            out["cpu_oracle"] = {"ms_per_tree_proposal": 1e3 * cpu, "cores": host_cores(), "kind": "port",
+                                 "sample": "%d tree proposals of chain 0 through the oracle's subtract/add Woodbury chain "
+                                           "(numpy, N x N copies as the reference makes)" % n_cpu}
+        del cb
+        torch.cuda.empty_cache()
+    return out
+
+
+def fitting_loop_probe(calls=100):
+    """SURVEY §8f-4 as far as the image allows (gpytorch / botorch absent: LeafGP itself is not buildable here):
+    TreeAgreementKernel.forward on RESIDENT CUDA tensors `calls` times in a row, as botorch's fitting loop evaluates
+    the kernel (src/bark/tree_kernels/tree_model_kernel.py:16-23; src/bofire_mixed/surrogates/leafgp.py:61-77):
+    per-call latency, and the share of calls served by the packed-forest cache (no host re-validation / upload)."""
+    import torch
+
+    from bark_amd import forest as bforest
+    from bark_amd import synthetic
+    from bark_amd.tree_kernels.tree_model_kernel import TreeAgreementKernel
+
+    rows = []
+    for n in (200, 1000, 2000):
+        X, _y, bounds, ft = synthetic.mixed_problem(n, seed=n)
+        forest = synthetic.sample_prior_forests(1, 50, bounds, ft, seed=n)[0]
+        kern = TreeAgreementKernel(forest, ft)
+        Xd = torch.from_numpy(X).cuda()
+        kern.forward(Xd, Xd)
+        torch.cuda.synchronize()
+        h0 = dict(bforest.pack_cache_stats)
+        t = time.perf_counter()
+        for _ in range(calls):
+            K = kern.forward(Xd, Xd)
+            dg = kern.forward(Xd, Xd, diag=True)
+        torch.cuda.synchronize()
+        per = (time.perf_counter() - t) / calls
+        h1 = dict(bforest.pack_cache_stats)
+        assert K.is_cuda and dg.is_cuda and bool((K.diagonal() == dg).all())
+        hits, misses = h1["hits"] - h0["hits"], h1["misses"] - h0["misses"]
+        rows.append({"N": n, "calls": calls, "ms_per_forward_plus_diag": 1e3 * per,
+                     "packed_forest_cache_hit_rate": hits / max(hits + misses, 1)})
+    return {"note": "gpytorch-free harness; LeafGP / botorch fitting itself stays blocked on gpytorch's absence", "rows": rows}
 
 
 def extras(args, wl, result, mll_host):
@@ -566,6 +769,9 @@ def extras(args, wl, result, mll_host):
         entry("small batch: N=4096, 16 forests", Workload(4096, d, m, 16, N, 0), 5)
         entry("small batch: N=4096, 8 forests", Workload(4096, d, m, 8, N, 0), 5)
         entry("lone matrix: N=4096, 1 forest", Workload(4096, d, m, 1, N, 0), 10, graph=True)
+        # the regime the reference itself runs in (BO with tens to hundreds of points: BASELINE configs[0] is N = 64)
+        for n_small in (64, 256, 512):
+            entry("small N: N=%d d=8 m=50, 256 forests" % n_small, Workload(n_small, 8, m, 256, n_small, 0), 20)
         torch.cuda.empty_cache()
         w5 = Workload(16384, 12, m, 1, 16384, 0, problem="mixed", include_scale=True)
         entry("c5 MLL: N=16384 mixed cat+int+cont, single forest", w5, 3)
@@ -580,6 +786,8 @@ def extras(args, wl, result, mll_host):
         lv = torch.empty((1, int(lib.bark_leaf_words(w2.pf.info_ref)), int(lib.bark_leaf_npad(1024))), dtype=torch.int32,
                          device=wl.Xd.device)
         K2 = torch.empty((1, 1024, 1024), dtype=torch.float64, device=wl.Xd.device)
+        _lib.check(lib.bark_leaf_codes_hip(_lib.ctx(), _lib.ptr(w2.pf.packed), w2.pf.info_ref, _lib.ptr(w2.Xd), 1024, 8,
+                                           _lib.ptr(lv), stream))  # real leaf codes of this forest, not uninitialised memory
         a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for it in range(21):
             if it == 1:
@@ -593,6 +801,11 @@ def extras(args, wl, result, mll_host):
                      "device_ms": g2, "achieved_GBs": (8.0 * 1024 * 1024 + 4.0 * m * 2048) / (g2 * 1e-3) / 1e9})
         del w2, lv, K2
         result["configs"] = cfgs
+
+    if not args.no_configs and N == 4096:
+        result["numpy_api_end_to_end"] = numpy_api_probe(wl)
+        result["sampler_step"] = sampler_step_probe(args, wl)
+        result["fitting_loop_harness"] = fitting_loop_probe()
 
     # ---- informational only: the leaf-space evaluation of the SAME MLLs (R x R system over the leaves instead
     # of the N x N matrix).  It does not do the Gram + Cholesky work the metric counts and is not part of `value`.

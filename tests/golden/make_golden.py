@@ -492,6 +492,120 @@ def g10_mcmc_posterior_forests():
          mll_sampler=mll_sampler(flat, noise_samples.reshape(-1), scale_samples.reshape(-1), X, y, ft))
 
 
+def g11_sampler_steps():
+    """Step-level trajectory of the reference's OWN Metropolis-Hastings step (`_step_bark_sampler`,
+    bark_sampler.py:217-284), run unmodified under the shim with recording hooks on the names it calls
+    (`get_tree_proposal`, `get_noise_scale_proposal`, `mll`, `np.random.uniform()`): for two independent chains, after a
+    warm-up, every per-tree proposal of three consecutive steps — the tree it replaces, the proposed tree, log_q_prior,
+    the uniform draw, new_mll, the decision, cur_mll after — and the noise/scale half of each step.  The GPU tests
+    replay it through ChainState.propose_tree / accept and ChainBatch.sweep_trees."""
+    _bofire_stubs()
+    import bark.fitting.bark_sampler as S
+
+    N, m, L, chains, warm, steps = 48, 8, 100, 2, 25, 3
+    X, y, bounds, ft = mixed_problem(N, seed=1111, d_cont=3, n_cat=1, n_int=1, cats=4)
+    w = np.array([0.5, 0.5, 1.0])
+    params = S.BARKTrainParamsNumba(
+        warmup_steps=0, num_samples=1, steps_per_sample=1, num_chains=1, alpha=0.95, beta=2.0,
+        proposal_weights=w / w.sum(), verbose=False, use_softplus_transform=True, sample_scale=True,
+        gamma_prior_shape=1.5, gamma_prior_rate=5.0)
+
+    log = {"prop": [], "mll": [], "u": [], "ns": []}
+    real_np, real_prop, real_ns, real_mll = S.np, S.get_tree_proposal, S.get_noise_scale_proposal, S.mll
+
+    class _Random:
+        def __getattr__(self, name):
+            return getattr(real_np.random, name)
+
+        def uniform(self, *a, **k):
+            v = real_np.random.uniform(*a, **k)
+            if not a and not k:  # the accept draws of bark_sampler.py:258,276 (proposals draw in their own modules)
+                log["u"].append(float(v))
+            return v
+
+    class _Np:
+        random = _Random()
+
+        def __getattr__(self, name):
+            return getattr(real_np, name)
+
+    def prop(nodes, *a):
+        old = np.array(nodes, copy=True)
+        new_nodes, log_q = real_prop(nodes, *a)
+        log["prop"].append((old, np.array(new_nodes, copy=True), float(log_q)))
+        return new_nodes, log_q
+
+    def ns(noise, scale, prm):
+        (nn, nsc), lq = real_ns(noise, scale, prm)
+        log["ns"].append((float(nn), float(nsc), float(lq)))
+        return (nn, nsc), lq
+
+    def mll_rec(*a):
+        v = real_mll(*a)
+        log["mll"].append(float(v))
+        return v
+
+    rec = {k: [] for k in ("old", "new", "log_q", "u", "new_mll", "accept", "cur_mll", "ns_prop", "ns_log_q", "ns_u",
+                           "ns_new_mll", "ns_accept", "noise_after", "scale_after", "forest_after", "mll_after")}
+    start = {"forest": [], "noise": [], "scale": [], "mll": []}
+    S.np, S.get_tree_proposal, S.get_noise_scale_proposal, S.mll = _Np(), prop, ns, mll_rec
+    try:
+        for c in range(chains):
+            np.random.seed(1111 + c)
+            forest = ref.empty_forest(m, L)
+            noise, scale = (0.1, 1.0) if c == 0 else (0.25, 0.8)
+            K_s = scale * F.forest_gram_matrix(forest, X, X, ft) + (1e-6 + noise) * np.eye(N)
+            K_inv, logdet = np.linalg.inv(K_s), np.linalg.slogdet(K_s)[1]
+            cur = QI.mll(K_inv, logdet, y)
+            for _ in range(warm):
+                forest, noise, scale, K_inv, logdet, cur = S._step_bark_sampler(forest, noise, scale, X, y, bounds, ft, params,
+                                                                                K_inv, logdet, cur)
+            start["forest"].append(np.array(forest, copy=True)); start["noise"].append(noise); start["scale"].append(scale)
+            start["mll"].append(float(cur))
+            per = {k: [] for k in rec}
+            for _ in range(steps):
+                for k in log:
+                    log[k].clear()
+                before = float(cur)
+                forest, noise, scale, K_inv, logdet, cur = S._step_bark_sampler(forest, noise, scale, X, y, bounds, ft, params,
+                                                                                K_inv, logdet, cur)
+                assert len(log["prop"]) == m and len(log["mll"]) == m + 1 and len(log["u"]) == m + 1 and len(log["ns"]) == 1
+                run, acc, curs = before, [], []
+                for t in range(m):  # bark_sampler.py:256-264
+                    a = bool(np.log(log["u"][t]) <= min(log["prop"][t][2] + log["mll"][t] - run, 0))
+                    if a:
+                        run = log["mll"][t]
+                    acc.append(a)
+                    curs.append(run)
+                a_ns = bool(np.log(log["u"][m]) <= min(log["ns"][0][2] + log["mll"][m] - run, 0))  # :272-276
+                if a_ns:
+                    run = log["mll"][m]
+                assert run == float(cur), (run, cur)  # the derived decisions reproduce the step's own outcome
+                per["old"].append(raw(np.stack([q[0] for q in log["prop"]])))
+                per["new"].append(raw(np.stack([q[1] for q in log["prop"]])))
+                per["log_q"].append([q[2] for q in log["prop"]]); per["u"].append(log["u"][:m])
+                per["new_mll"].append(log["mll"][:m]); per["accept"].append(acc); per["cur_mll"].append(curs)
+                per["ns_prop"].append(log["ns"][0][:2]); per["ns_log_q"].append(log["ns"][0][2]); per["ns_u"].append(log["u"][m])
+                per["ns_new_mll"].append(log["mll"][m]); per["ns_accept"].append(a_ns)
+                per["noise_after"].append(noise); per["scale_after"].append(scale)
+                per["forest_after"].append(raw(np.array(forest, copy=True))); per["mll_after"].append(float(cur))
+            for k in rec:
+                rec[k].append(per[k])
+    finally:
+        S.np, S.get_tree_proposal, S.get_noise_scale_proposal, S.mll = real_np, real_prop, real_ns, real_mll
+    arrays = {k: np.array(v) for k, v in rec.items()}
+    n_acc = int(arrays["accept"].sum())
+    assert 0 < n_acc < arrays["accept"].size, "the trajectory should hold both accepted and rejected proposals"
+    save("g11_sampler_steps",
+         {"src": "bark_sampler.py:217-284 `_step_bark_sampler` run unmodified under the shim (np.random.seed(1111 + chain)), "
+                 "with recording wrappers on get_tree_proposal / get_noise_scale_proposal / mll / np.random.uniform()",
+          "layout": "(chains, steps, trees, ...) for the per-tree arrays, (chains, steps, ...) for the noise/scale half",
+          "tree_accepts": n_acc, "tree_proposals": int(arrays["accept"].size), "ns_accepts": int(arrays["ns_accept"].sum())},
+         X=X, y=y, bounds=bounds, feat_types=ft, start_forest=raw(np.stack(start["forest"])),
+         start_noise=np.array(start["noise"]), start_scale=np.array(start["scale"]), start_mll=np.array(start["mll"]),
+         **arrays)
+
+
 if __name__ == "__main__":
     g1_kat_tree()
     g2_two_tree_kat()
@@ -503,6 +617,7 @@ if __name__ == "__main__":
     g8_batched_mll()
     g9_woodbury()
     g10_mcmc_posterior_forests()
+    g11_sampler_steps()
     # the reference tree must stay clean
     import subprocess
 

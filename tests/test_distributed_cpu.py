@@ -111,6 +111,29 @@ def test_bench_launches_its_own_workers_from_a_plain_shell(gpus):
     r = _run_bench(["bench.py", "--gpus", str(gpus), "--selftest-launcher"])
     assert r["ranks_reached"] == gpus and r["gather_ok"] and r["launched_by"] == "bench.py"
     assert r["scaling"] == "weak" and r["total"] == 256 * gpus and r["local"] == 256
+    if gpus > 1:  # the second timed region of a weak run: BASELINE configs[3], 512 samples sharded over the ranks
+        assert r["c4_strong"] == {"total": 512, "local": 256, "gather_ok": True, "scaling": "strong"}
+        assert r["collective_backend"] == "gloo" and r["collective_backend_requested"] == "gloo" and r["rccl_ranks_seen"] is None
+    else:
+        assert r["c4_strong"] is None and r["collective_backend"] is None
+
+
+def test_bench_rccl_failure_is_fatal_unless_the_fallback_is_asked_for():
+    """RCCL cannot come up on this CPU-only box.  Default (--require-rccl): every worker exits non-zero, no JSON line.
+    --no-require-rccl: the gather falls back to gloo inside the same worker processes and the line says so."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["BARK_BENCH_BACKEND"] = "nccl"
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--selftest-launcher"], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=180)
+    assert out.returncode != 0 and "--require-rccl is in force" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    r = _run_bench(["bench.py", "--gpus", "2", "--selftest-launcher", "--no-require-rccl"], {"BARK_BENCH_BACKEND": "nccl"})
+    assert r["collective_backend_requested"] == "nccl" and r["collective_backend"] == "gloo" and r["rccl_ranks_seen"] is None
+    assert r["gather_ok"] and r["c4_strong"]["gather_ok"]
 
 
 def test_bench_strong_scaling_shards_c4():

@@ -1,5 +1,5 @@
-"""BASELINE.json configs c1, c2, c4 and c5 at their stated sizes (c3: test_gpu_parity.py::test_c3_full_size_properties
-and the bench's in-run check).  Inputs follow SURVEY §8d; the checker is the CPU oracle (LU route = the reference's
+"""BASELINE.json configs c1 … c5 at their stated sizes (c3 at B = 256 here; its size-independent properties are in
+test_gpu_parity.py::test_c3_full_size_properties).  Inputs follow SURVEY §8d; the checker is the CPU oracle (LU route = the reference's
 arithmetic) where it finishes in seconds and a CPU Cholesky for the one N = 16384 matrix of c5."""
 import os
 import socket
@@ -44,6 +44,89 @@ def test_c2_n1024_single_forest():
     got = fit.batched_mll(F, [0.1], [1.0], X, y, ft, include_scale=True, include_2pi=True)
     want = orc.batched_mll(F, [0.1], [1.0], X, y, ft, include_scale=True, include_2pi=True)
     assert np.allclose(got, want, rtol=MLL_RTOL, atol=MLL_ATOL), (got, want)
+
+
+def test_c3_b256_plain_schedule():
+    """configs[2], the headline shape exactly: N = 4096, d = 8, m = 50, B = 256 forests seeded 4096 + b, noise
+    U[0.05, 0.15) (examples/mcmc/mcmc_record_mll.py:57-74 convention).  256 resident matrices of 32 block
+    rows is the one shape class that takes Sweep's PLAIN schedule with ragged-round splitting off (bc % 256 == 0 and
+    nrb > 16).  First / middle / last sample against the oracle's LU route, bit-reproducibility of the call, and
+    agreement with the pipelined schedule (chunk = 64)."""
+    import torch
+
+    import bark_amd.fitting as fit
+    from bark_amd import synthetic as syn
+    from oracle import oracle as orc
+
+    N, B, m = 4096, 256, 50
+    X, y, bounds, ft = syn.unit_cube_problem(N, 8, seed=N)
+    F = syn.sample_prior_forests(B, m, bounds, ft, seed=N)
+    noise = np.random.default_rng(N).uniform(0.05, 0.15, B)
+    Xd = torch.from_numpy(X).cuda()
+    kw = dict(include_scale=False, include_2pi=True)
+    got = fit.batched_mll(F, noise, None, Xd, y, ft, chunk=256, **kw)  # a non-PD pivot (info != 0) raises LinAlgError
+    again = fit.batched_mll(F, noise, None, Xd, y, ft, chunk=256, **kw)
+    assert np.array_equal(got, again)
+    piped = fit.batched_mll(F, noise, None, Xd, y, ft, chunk=64, **kw)
+    assert np.allclose(got, piped, rtol=1e-12, atol=0.0)
+    pick = [0, B // 2, B - 1]
+    want = orc.batched_mll(F[pick], noise[pick], None, X, y, ft, **kw)
+    assert np.allclose(got[pick], want, rtol=MLL_RTOL, atol=MLL_ATOL), (got[pick], want)
+    assert np.isfinite(got).all()
+
+
+def test_plain_schedule_n2200_b256():
+    """A second shape of the plain schedule's class (18 block rows > 16, 256 resident matrices), ragged N, mixed
+    feature types, scale included."""
+    import bark_amd.fitting as fit
+    from bark_amd import synthetic as syn
+    from oracle import oracle as orc
+
+    N, B, m = 2200, 256, 50
+    X, y, bounds, ft = syn.mixed_problem(N, seed=2200)
+    F = syn.sample_prior_forests(B, m, bounds, ft, seed=2201)
+    rng = np.random.default_rng(2202)
+    noise, scale = rng.uniform(0.05, 0.3, B), rng.uniform(0.6, 1.5, B)
+    kw = dict(include_scale=True, include_2pi=False)
+    got = fit.batched_mll(F, noise, scale, X, y, ft, chunk=256, **kw)
+    assert np.array_equal(got, fit.batched_mll(F, noise, scale, X, y, ft, chunk=256, **kw))
+    assert np.allclose(got, fit.batched_mll(F, noise, scale, X, y, ft, chunk=96, **kw), rtol=1e-12, atol=0.0)
+    pick = [0, 1, 127, 128, 255]
+    want = orc.batched_mll(F[pick], noise[pick], scale[pick], X, y, ft, **kw)
+    assert np.allclose(got[pick], want, rtol=MLL_RTOL, atol=MLL_ATOL), (got[pick], want)
+
+
+def test_c5_b4_variant():
+    """SURVEY §8d's B = 4 variant of configs[4]: four N = 16384 mixed-type matrices resident at once (the pipelined
+    schedule with split-K launches instead of the lone matrix's).  Leaf indices of all four forests bit-exact, one
+    MLL against a CPU Cholesky, forest 0 equal to the B = 1 call to rounding."""
+    import scipy.linalg as sla
+    import torch
+
+    import bark_amd.fitting as fit
+    import bark_amd.forest as bf
+    from bark_amd import synthetic as syn
+    from oracle import oracle as orc
+
+    N, B = 16384, 4
+    X, y, bounds, ft = syn.mixed_problem(N, seed=16384)
+    F = syn.sample_prior_forests(B, 50, bounds, ft, seed=16384)
+    noise, scale = np.array([0.1, 0.07, 0.13, 0.2]), np.array([1.0, 0.8, 1.3, 1.1])
+    for b in range(B):
+        assert np.array_equal(bf.pass_through_forest(F[b], X, ft), orc.pass_through_forest(F[b], X, ft))
+    Xd = torch.from_numpy(X).cuda()
+    kw = dict(include_scale=True, include_2pi=False)
+    got = fit.batched_mll(F, noise, scale, Xd, y, ft, **kw)
+    one = fit.batched_mll(F[:1], noise[:1], scale[:1], Xd, y, ft, **kw)
+    assert np.allclose(got[:1], one, rtol=1e-12, atol=0.0)
+    b = 2
+    K = orc.forest_gram_matrix(F[b], X, X, ft)
+    K *= scale[b]
+    K[np.diag_indices(N)] += 1e-6 + noise[b]
+    c = sla.cholesky(K, lower=True, check_finite=False, overwrite_a=True)
+    z = sla.solve_triangular(c, y, lower=True, check_finite=False)
+    mll0 = 0.5 * (-(z.T @ z)[0, 0] - 2.0 * np.log(np.diag(c)).sum())
+    assert abs(got[b] - mll0) <= MLL_ATOL + MLL_RTOL * abs(mll0), (got[b], mll0)
 
 
 def test_c5_n16384_mixed_posterior_10k_candidates():

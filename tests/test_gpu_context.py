@@ -138,6 +138,37 @@ def test_sweep_is_hipgraph_capturable(env):
     assert np.allclose(eager3[:2].cpu().numpy(), want, rtol=1e-9, atol=1e-8)
 
 
+def test_thread_exit_frees_its_context(env):
+    """A host thread that used the library and exits WITHOUT release_ctx() must not leak its bark_ctx (helper streams,
+    events, pinned page, grow-only hipMalloc scratch): the per-thread owner object is collected with the thread's
+    locals and its finalizer destroys the context."""
+    import gc
+    import weakref
+
+    torch, L = env.torch, env.lib
+    torch.cuda.synchronize()
+    gc.collect()
+    free_before = torch.cuda.mem_get_info()[0]
+    seen = {}
+
+    def work():
+        torch.cuda.set_device(0)
+        ws = L.workspace(1 << 30)  # 1 GiB of scratch owned by this thread's context
+        seen["bytes"] = L.workspace_bytes()
+        seen["held"] = free_before - torch.cuda.mem_get_info()[0]
+        seen["owner"] = weakref.ref(L._tls.handles[0])
+        del ws
+
+    t = threading.Thread(target=work)
+    t.start()
+    t.join()
+    gc.collect()
+    assert seen["bytes"] >= 1 << 30 and seen["held"] >= (1 << 30) - (64 << 20)
+    assert seen["owner"]() is None  # the owner died with the thread ...
+    torch.cuda.synchronize()
+    assert free_before - torch.cuda.mem_get_info()[0] < (64 << 20)  # ... and the scratch went back to the driver
+
+
 @pytest.mark.parametrize("N", [300, 301])
 def test_device_side_metropolis_sweep_matches_host_loop(env, N):
     """ChainBatch.sweep_trees (decision on the device, one read-back per sweep) against the per-tree host loop of
@@ -170,6 +201,72 @@ def test_device_side_metropolis_sweep_matches_host_loop(env, N):
     final[mask] = prop[mask]
     want = env.orc.batched_mll(final, noise, scale, X, y, ft, include_scale=True, include_2pi=False)
     assert np.allclose(dev.mll, want, rtol=1e-9, atol=1e-8)
+
+
+def test_g11_reference_sampler_steps_replayed_on_the_device(env):
+    """tests/golden/g11_sampler_steps.npz — the reference's own `_step_bark_sampler` (bark_sampler.py:217-284) recorded
+    proposal by proposal — replayed (a) per chain through ChainState.propose_tree / accept / propose_noise_scale and
+    (b) for both chains at once through ChainBatch.sweep_trees with the decision on the device: identical Metropolis
+    decisions, new_mll and cur_mll within rtol 1e-9 of the reference's values."""
+    from conftest import load_golden
+
+    fit, orc = env.fit, env.orc
+    g = load_golden("g11_sampler_steps")
+    X, y, ft = g["X"], g["y"], g["feat_types"]
+    chains, steps, m = g["accept"].shape
+    tol = dict(rtol=1e-9, atol=1e-8)
+    # (a) one chain at a time, host-side decisions from device MLLs
+    for c in range(chains):
+        forest = orc.nodes_from_raw(g["start_forest"][c]).copy()
+        noise, scale = float(g["start_noise"][c]), float(g["start_scale"][c])
+        st = fit.ChainState.from_forest(forest, noise, scale, X, y, ft)
+        assert np.isclose(st.mll, g["start_mll"][c], **tol)
+        for s in range(steps):
+            old, new = orc.nodes_from_raw(g["old"][c, s]), orc.nodes_from_raw(g["new"][c, s])
+            for t in range(m):
+                before = st.mll
+                val = st.propose_tree(old[t], new[t], X, ft, scale, m)
+                assert np.isclose(val, g["new_mll"][c, s, t], **tol), (c, s, t, val, g["new_mll"][c, s, t])
+                acc = bool(np.log(g["u"][c, s, t]) <= min(g["log_q"][c, s, t] + val - before, 0))
+                assert acc == bool(g["accept"][c, s, t]), (c, s, t)
+                if acc:
+                    st.accept()
+                    forest[t] = new[t]
+                assert np.isclose(st.mll, g["cur_mll"][c, s, t], **tol)
+            nn, nsc = (float(v) for v in g["ns_prop"][c, s])
+            before = st.mll
+            val = st.propose_noise_scale(forest, nn, nsc, X, ft)
+            assert np.isclose(val, g["ns_new_mll"][c, s], **tol)
+            acc = bool(np.log(g["ns_u"][c, s]) <= min(g["ns_log_q"][c, s] + val - before, 0))
+            assert acc == bool(g["ns_accept"][c, s])
+            if acc:
+                st.accept()
+                noise, scale = nn, nsc
+            assert np.isclose(st.mll, g["mll_after"][c, s], **tol)
+            assert np.array_equal(forest, orc.nodes_from_raw(g["forest_after"][c, s]))
+    # (b) both chains, one device-side sweep per step (the noise/scale half rebuilds the batch, as the reference's
+    # full inv + slogdet does)
+    forests = orc.nodes_from_raw(g["start_forest"]).copy()
+    noise, scale = g["start_noise"].copy(), g["start_scale"].copy()
+    cb = fit.ChainBatch.from_forests(forests, noise, scale, X, y, ft)
+    for s in range(steps):
+        old, new = orc.nodes_from_raw(g["old"][:, s]), orc.nodes_from_raw(g["new"][:, s])
+        assert np.array_equal(old, forests)
+        mask = cb.sweep_trees(old, new, g["log_q"][:, s], np.log(g["u"][:, s]), X, ft, scale, m)
+        assert np.array_equal(mask, g["accept"][:, s])
+        forests[mask] = new[mask]
+        assert np.allclose(cb.mll, g["cur_mll"][:, s, -1], **tol)
+        vals = fit.batched_mll(forests, g["ns_prop"][:, s, 0], g["ns_prop"][:, s, 1], X, y, ft, include_scale=True,
+                               include_2pi=False)
+        assert np.allclose(vals, g["ns_new_mll"][:, s], **tol)
+        acc = np.log(g["ns_u"][:, s]) <= np.minimum(g["ns_log_q"][:, s] + vals - cb.mll, 0)
+        assert np.array_equal(acc, g["ns_accept"][:, s])
+        noise = np.where(acc, g["ns_prop"][:, s, 0], noise)
+        scale = np.where(acc, g["ns_prop"][:, s, 1], scale)
+        assert np.array_equal(noise, g["noise_after"][:, s]) and np.array_equal(scale, g["scale_after"][:, s])
+        if acc.any():
+            cb = fit.ChainBatch.from_forests(forests, noise, scale, X, y, ft)
+        assert np.allclose(cb.mll, g["mll_after"][:, s], **tol)
 
 
 def test_singular_low_rank_system_raises_linalgerror(env):

@@ -16,7 +16,8 @@ CASES = [
     (1300, 40, 30, 0, 24), (1500, 9, 50, 0, None), (2100, 2, 50, 0, None), (2500, 20, 50, 0, None),
     (640, 16, 50, 90, None), (1000, 70, 25, 130, None), (1400, 3, 50, 300, None),
     # filled chunks of >= 8 block rows whose size is not a multiple of 256: the pipelined schedule (Sweep::step_pipelined),
-    # generated and materialised Gram, candidate columns, a shorter last chunk, and its plain-schedule neighbour B = 256
+    # generated and materialised Gram, candidate columns, a shorter last chunk, and B = 256 at 9 block rows (pipelined as well: the plain schedule needs more
+    # than 16 block rows beside the multiple of 256 — tests/test_gpu_configs.py::test_c3_b256_plain_schedule, ::test_plain_schedule_n2200_b256)
     (1100, 130, 50, 0, None), (1300, 200, 20, 0, 120), (2100, 70, 50, 0, None), (1000, 150, 25, 130, None),
     (1500, 100, 30, 200, None), (1100, 256, 50, 0, None),
     # split-K layout with look-ahead, its last step bound by the bulk (second bulk stream): one small matrix, many candidate

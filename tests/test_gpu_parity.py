@@ -758,6 +758,9 @@ def test_torch_tensors_stay_on_device(B):
     Xc = torch.from_numpy(g["X"])
     assert np.array_equal(kern.forward(Xc, Xc).numpy(), g["K"][0])
     assert torch.equal(kern.forward(Xc, Xc, diag=True), torch.ones(64))
+    dg = kern.forward(Xd, Xd, diag=True)  # device inputs: the diagonal of the device Gram, on the device, in its dtype
+    full = kern.forward(Xd, Xd)
+    assert dg.is_cuda and dg.dtype == full.dtype and torch.equal(dg, full.diagonal())
 
 
 # ------------------------------------------------------------------ full-size properties ----------

@@ -169,3 +169,51 @@ def test_g10_forests_from_the_reference_mcmc_sampler():
     ex = orc.batched_mll(forest, g["noise"], None, X, y, ft, include_scale=False, include_2pi=True)
     sa = orc.batched_mll(forest, g["noise"], g["scale"], X, y, ft, include_scale=True, include_2pi=False)
     assert np.allclose(ex, g["mll_example"], rtol=1e-12) and np.allclose(sa, g["mll_sampler"], rtol=1e-12)
+
+
+def test_g11_step_trajectory_of_the_reference_sampler():
+    """`_step_bark_sampler` (bark_sampler.py:217-284) recorded proposal by proposal: the oracle's restated Woodbury
+    chain (subtract old leaf vectors, add new ones, quick_inverse.mll) reproduces every new_mll, every Metropolis
+    decision and the running cur_mll; the noise/scale half by the full LU rebuild, as the reference does."""
+    g = load_golden("g11_sampler_steps")
+    X, y, ft = g["X"], g["y"], g["feat_types"]
+    N = X.shape[0]
+    chains, steps, m = g["accept"].shape
+    for c in range(chains):
+        forest = RAW(g["start_forest"][c]).copy()
+        noise, scale = float(g["start_noise"][c]), float(g["start_scale"][c])
+        K_s = scale * orc.forest_gram_matrix(forest, X, X, ft) + (1e-6 + noise) * np.eye(N)
+        K_inv, logdet = np.linalg.inv(K_s), np.linalg.slogdet(K_s)[1]
+        cur = orc.mll(K_inv, logdet, y)
+        assert np.isclose(cur, g["start_mll"][c], rtol=1e-10)
+        for s in range(steps):
+            old, new = RAW(g["old"][c, s]), RAW(g["new"][c, s])
+            s_sqrtm = np.sqrt(scale / m)
+            for t in range(m):
+                assert np.array_equal(old[t], forest[t])  # the proposal replaces the chain's current tree t
+                U_old = s_sqrtm * orc.get_leaf_vectors(old[t], X, ft)
+                U_new = s_sqrtm * orc.get_leaf_vectors(new[t], X, ft)
+                K1 = orc.low_rank_inv_update(K_inv, U_old, subtract=True)
+                d1 = orc.low_rank_det_update(K_inv, U_old, logdet, subtract=True)
+                K2 = orc.low_rank_inv_update(K1, U_new)
+                d2 = orc.low_rank_det_update(K1, U_new, d1)
+                new_mll = orc.mll(K2, d2, y)
+                assert np.isclose(new_mll, g["new_mll"][c, s, t], rtol=1e-9, atol=1e-9)
+                acc = bool(np.log(g["u"][c, s, t]) <= min(g["log_q"][c, s, t] + new_mll - cur, 0))
+                assert acc == bool(g["accept"][c, s, t])
+                if acc:
+                    K_inv, logdet, cur = K2, d2, new_mll
+                    forest[t] = new[t]
+                assert np.isclose(cur, g["cur_mll"][c, s, t], rtol=1e-9, atol=1e-9)
+            nn, nsc = g["ns_prop"][c, s]
+            K_s = nsc * orc.forest_gram_matrix(forest, X, X, ft) + (1e-6 + nn) * np.eye(N)
+            Kn, dn = np.linalg.inv(K_s), np.linalg.slogdet(K_s)[1]
+            ns_mll = orc.mll(Kn, dn, y)
+            assert np.isclose(ns_mll, g["ns_new_mll"][c, s], rtol=1e-9, atol=1e-9)
+            acc = bool(np.log(g["ns_u"][c, s]) <= min(g["ns_log_q"][c, s] + ns_mll - cur, 0))
+            assert acc == bool(g["ns_accept"][c, s])
+            if acc:
+                K_inv, logdet, cur, noise, scale = Kn, dn, ns_mll, float(nn), float(nsc)
+            assert noise == g["noise_after"][c, s] and scale == g["scale_after"][c, s]
+            assert np.array_equal(forest, RAW(g["forest_after"][c, s]))
+            assert np.isclose(cur, g["mll_after"][c, s], rtol=1e-9, atol=1e-9)
