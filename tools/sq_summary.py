@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Fold one rocprofv3 --pmc pass of SQ / GRBM counters into per-kernel sums and the derived figures DESIGN.md quotes:
-   mfma_busy_frac   = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CYCLES)      (busy cycles summed over a CU's 4 SIMDs)
+   mfma_busy_frac   = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024)   (MFMA-pipe busy cycles summed over the
+                      chip's 1024 SIMDs, against the shader cycles the dispatches lasted: GRBM_GUI_ACTIVE sums 8 XCDs)
    f64_mfma_flops   = SQ_INSTS_VALU_MFMA_MOPS_F64 * 512                     (the counter ticks in units of 512 flops)
    eff_clock_GHz    = GRBM_GUI_ACTIVE / 8 / kernel time                     (MI355X_MICROARCH.md, DVFS give-back)
    python3 tools/sq_summary.py <pmc dir> out.json N B calls"""
@@ -40,10 +41,10 @@ def main():
             c[row["Counter_Name"]] = c.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
     for k, e in per.items():
         c = e["counters"]
-        busy, mfma = c.get("SQ_BUSY_CYCLES", 0.0), c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+        gui, mfma = c.get("GRBM_GUI_ACTIVE", 0.0), c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
         e["derived"] = {}
-        if busy > 0:
-            e["derived"]["mfma_busy_frac_of_simd_cycles"] = mfma / (4.0 * busy)
+        if gui > 0:
+            e["derived"]["mfma_busy_frac_of_simd_cycles"] = mfma / (gui / 8.0 * 1024.0)
         if c.get("SQ_INSTS_VALU_MFMA_MOPS_F64"):
             e["derived"]["f64_mfma_flops"] = c["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0
             if e["ns"] > 0:
