@@ -46,6 +46,7 @@ class MllTiming(ctypes.Structure):
 SIGNATURES = {
     "bark_version": (ci, []),
     "bark_last_error": (ctypes.c_char_p, []),
+    "bark_device_wait": (ci, [ci]),
     "bark_forest_pack_info": (ci, [vp, i64, i64, i64, vp, i64, ctypes.POINTER(PackInfo)]),
     "bark_forest_pack": (ci, [vp, vp, i64, ctypes.POINTER(PackInfo), vp]),
     "bark_ctx_create": (ci, [ci, ctypes.POINTER(vp)]),

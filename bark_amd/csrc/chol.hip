@@ -45,6 +45,7 @@
 // D reg v: row = (l>>4) + 4v, col = l&15.  Both GEMM operands are "k-major" panels of U (rows = k,
 // 128 contiguous columns), so a panel row is one 1 KiB coalesced wave load and the LDS image
 // As[k][128(+16 pad)] is read conflict-free by ds_read_b64 (row stride 1152 B == 128 mod 256).
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <mutex>
@@ -278,6 +279,10 @@ struct Mats {
     const double *shift;    // (Bc,) or nullptr (no-null kernel)
     const double *noise;    // (Bc,)
     int nW, m, N;  // dwords of leaf ids per point, trees, real points
+    // device-side hand-over of row-launch completion to the caller's stream (chain-bound schedules, see Sweep):
+    // sync[0], sync[1] = progress counters of the two row streams, sync[2] = timed-out waits, sync[3] = progress of
+    // the caller's stream (diag_kernel(j) stores j + 1 when it starts: solve(j-1) has retired).  Zeroed per chunk.
+    int32_t *sync;
 };
 
 constexpr size_t W_STRIDE = (size_t)2 * NB * NB;  // doubles per matrix in Mats::W
@@ -588,7 +593,15 @@ __device__ __forceinline__ void diag_g(const double *__restrict__ Up, long ld, c
 // nkb: trailing block rows of U still to be applied to the stored diagonal tile, D = P - sum_{j-nkb <= k < j} U[k,j]'U[k,j]
 // (1 in the plain schedule, 2 in the pipelined one, 0 for j == 0).
 // want_g (pipelined schedule): also rows 0..127 of Mats::W := -U[j-1,j] W_j, the dense half of solve_kernel<1>'s left operand.
-__global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb, int want_g) {
+// wait_slot >= -1 (chain-bound chunks): the launch stores its block step in p.sync[3] when it starts — the helper
+// streams' gate kernels wait for that instead of an event recorded between solve(j-1) and this kernel.  wait_slot == -2: off.
+// wait_slot >= 0: before it ends, the workgroup waits (bounded: ~2 s, then info = -3) until the progress counter
+// p.sync[wait_slot] has reached wait_value — the row launch whose tiles the NEXT kernel of this stream (solve(j)) reads
+// has retired.  This replaces an event wait between diag(j) and solve(j) on the caller's stream: an unresolved
+// cross-stream event wait costs ~5-13 us there, kernels back to back 0.8 us (tools/gap_probe.hip), and the row launch
+// is normally long done.  Only this kernel spins — at most 32 workgroups, on CUs the row kernels do not need — and what
+// it waits for never waits for it (the row launch was released by an event recorded before this kernel was enqueued).
+__global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb, int want_g, int wait_slot, int wait_value) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, b = blockIdx.x;
     const Lane q = lane_of(tid);
@@ -597,6 +610,8 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
     double *tile = Ab + (size_t)j * NB * p.ld + (size_t)j * NB;
     // operands of the kernel's last phase, requested now so their latency hides behind the factorisation
     // (solve_kernel(j-1) finished updating y_j before this launch)
+    if (wait_slot >= -1 && b == 0 && tid == 0 && p.sync)  // this launch has started: everything before it on this stream is done
+        __hip_atomic_store(p.sync + 3, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const double y_in = tid < NB ? p.yz[(size_t)b * p.nrb * NB + (size_t)j * NB + tid] : 0.0;
     const double acc_quad = tid == 0 ? p.accum[(size_t)b * 2 + 0] : 0.0;
     const double acc_logdet = tid == 0 ? p.accum[(size_t)b * 2 + 1] : 0.0;
@@ -769,7 +784,44 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
     if (tid == 0) {  // wave 0 ran factor16: its logsum / bad are the matrix's
         p.accum[(size_t)b * 2 + 0] = acc_quad + (red[0] + red[1]);
         p.accum[(size_t)b * 2 + 1] = acc_logdet + 2.0 * logsum;
-        if (bad && info_in == 0) p.info[b] = j * NB + bad;
+        int code = (bad && info_in == 0) ? j * NB + bad : 0;
+        if (wait_slot >= 0) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+            const int32_t *flag = p.sync + wait_slot;
+            bool ok = true;
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < wait_value) {
+                __builtin_amdgcn_s_sleep(8);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {  // 2 s: the row stream is not running beside us
+                    ok = false;
+                    break;
+                }
+            }
+            if (!ok) {
+                atomicAdd(p.sync + 2, 1);
+                code = -3;
+            }
+        }
+        if (code != 0 && (info_in == 0 || code == -3)) p.info[b] = code;
+    }
+}
+
+// the row stream `slot` has finished everything up to block step `value` (one thread; runs after the row kernels
+// of that step in stream order, so their stores are complete and released when it starts)
+__global__ void sync_publish_kernel(int32_t *sync, int slot, int value) {
+    __hip_atomic_store(sync + slot, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Gate of a helper stream: one lane waits (bounded: ~2 s, then sync[2]++ and on it goes — the call ends with info = -3)
+// until the caller's stream has reached block step `value` (diag_kernel publishes it when it starts); the row kernels
+// behind the gate in stream order start once it retires.  The kernel they depend on was enqueued before this one.
+__global__ void sync_gate_kernel(int32_t *sync, int slot, int value) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+    while (__hip_atomic_load(sync + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value) {
+        __builtin_amdgcn_s_sleep(4);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+            atomicAdd(sync + 2, 1);
+            break;
+        }
     }
 }
 
@@ -1158,10 +1210,11 @@ __global__ __launch_bounds__(THREADS, 2) void vtv_kernel(Mats p, int nct, int C,
 
 // yz[b][:] = y (zero padded); accum = 0; info = 0
 __global__ void init_rhs_kernel(const double *__restrict__ y, int N, int npad, double *yz, double *accum,
-                                int32_t *info) {
+                                int32_t *info, int32_t *sync) {
     const int b = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < npad) yz[(size_t)b * npad + i] = i < N ? y[i] : 0.0;
+    if (sync && b == 0 && blockIdx.x == 0 && threadIdx.x < 4) sync[threadIdx.x] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         accum[(size_t)b * 2] = 0.0;
         accum[(size_t)b * 2 + 1] = 0.0;
@@ -1177,10 +1230,11 @@ __global__ void fault_info_kernel(const int32_t *fault, int32_t *info, int Bc) {
 
 // quick_inverse.py:38 / mcmc_record_mll.py:73
 __global__ void finish_mll_kernel(const double *accum, int Bc, int N, int include_2pi, double *mll, const int32_t *fault,
-                                  int32_t *info) {
+                                  int32_t *info, const int32_t *sync) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= Bc) return;
     if (*fault) info[b] = -1;
+    if (sync && sync[2] != 0) info[b] = -3;  // a device-side wait of this chunk timed out: its results are not valid
     double v = -accum[(size_t)b * 2] - accum[(size_t)b * 2 + 1];
     if (include_2pi) v = v - (double)N * log(2.0 * M_PI);
     mll[b] = 0.5 * v;
@@ -1354,10 +1408,18 @@ constexpr int PIPE_MIN_NRB = BARK_PIPE_MIN_NRB;  // fewer block rows: plain sche
 // a solve of at most this many workgroups after sharing its tiles' columns out goes narrow (look-ahead / pipelined schedule)
 constexpr long SOLVE_NARROW_MAX_WGS = BARK_SOLVE_NARROW_MAX_WGS, PIPE_NARROW_MAX_WGS = BARK_PIPE_NARROW_MAX_WGS;
 
+#ifndef BARK_DEVWAIT_MAX_BC
+#define BARK_DEVWAIT_MAX_BC 32
+#endif
+// chunks of at most this many matrices hand row-launch completion over to the caller's stream by a device-side counter
+// (diag_kernel waits at its end) instead of an event: their block steps are bound by diag -> solve -> diag, and the
+// waiting workgroups (one per matrix) hold few slots
+constexpr int DEVWAIT_MAX_BC = BARK_DEVWAIT_MAX_BC;
+
 struct Layout {
     int64_t npad, cpad, ncols, ld, W;
     bool splitk;  // chunk too small to fill the chip with one workgroup per tile: slab scratch reserved
-    size_t off_A, off_W, off_yz, off_acc, off_leafx, off_leafc, off_slab, total;
+    size_t off_A, off_W, off_yz, off_acc, off_sync, off_leafx, off_leafc, off_slab, total;
 };
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1378,6 +1440,8 @@ Layout make_layout(int64_t N, int64_t C, int64_t m, int64_t Bc) {
     o = align256(o + (size_t)Bc * L.npad * sizeof(double));
     L.off_acc = o;
     o = align256(o + (size_t)Bc * 2 * sizeof(double));
+    L.off_sync = o;
+    o = align256(o + 64);
     L.off_leafx = o;
     o = align256(o + (size_t)Bc * L.W * L.npad * sizeof(uint32_t));
     L.off_leafc = o;
@@ -1463,6 +1527,10 @@ struct Sweep {
     bark_ctx *res = nullptr;
     int nrb = 0, ncb = 0;
     bool fused = false, splitk = false, pipelined = false;
+    // chain-bound chunks (few matrices): diag_kernel(j) itself waits, at its end, for the row launch solve(j) depends on
+    // (device-side progress counter) instead of an event wait on the caller's stream; see diag_kernel
+    bool dev_wait = false;
+    bool dev_gate = false;  // ... and the helper streams are released by gate kernels instead of an event record
     int rep = 0;
     double *slabs = nullptr;
     // timing mode only: one event pair per launch, recorded on the stream of the launch
@@ -1495,7 +1563,20 @@ struct Sweep {
         return BARK_OK;
     }
 
-    int launch_diag(int j, int nkb, int want_g = 0) {
+    int publish(hipStream_t st, int slot, int value) {
+        hipLaunchKernelGGL(sync_publish_kernel, dim3(1), dim3(1), 0, st, p.sync, slot, value);
+        BARK_LAUNCH_CHECK();
+        return BARK_OK;
+    }
+
+    int gate(hipStream_t st, int value) {  // st proceeds once the caller's stream has started diag(value - 1)
+        hipLaunchKernelGGL(sync_gate_kernel, dim3(1), dim3(1), 0, st, p.sync, 3, value);
+        BARK_LAUNCH_CHECK();
+        return BARK_OK;
+    }
+
+    // wait_slot: -2 no device-side hand-over; -1 publish the start only; 0 / 1: also wait for that row stream at the end
+    int launch_diag(int j, int nkb, int want_g = 0, int wait_slot = -2, int wait_value = 0) {
         int r;
         if (timed) diag_marks.push_back(ev.size());
         if ((r = mark_on(main))) return r;
@@ -1505,7 +1586,7 @@ struct Sweep {
         // pipelined schedule's row launches retire workgroups continuously: there the whole-CU request stays the
         // better choice — one N = 16384 matrix 26.6 against 28.3 ms, N = 4096 x 8 4.87 against 5.34.)
         const bool exclusive = p.Bc <= DIAG_EXCLUSIVE_MAX_BC && !lookahead(j + 1);
-        hipLaunchKernelGGL(diag_kernel, dim3((unsigned)p.Bc), dim3(THREADS), exclusive ? DIAG_LDS_EXCLUSIVE : DIAG_LDS, main, p, j, nkb, want_g);
+        hipLaunchKernelGGL(diag_kernel, dim3((unsigned)p.Bc), dim3(THREADS), exclusive ? DIAG_LDS_EXCLUSIVE : DIAG_LDS, main, p, j, nkb, want_g, wait_slot, wait_value);
         BARK_LAUNCH_CHECK();
         return mark_on(main);
     }
@@ -1623,8 +1704,43 @@ struct Sweep {
         const int S = la ? split_factor(j, j - 1, la_slots(j)) : split_factor(j, j);
         // j == 0: with a materialised A the tiles T = A are in place; in fused-Gram sweeps the K = 0 launch writes them
         const bool has_rows = (j >= 1 || fused) && n_tiles > 0;
-        if (has_rows && (r = fork(6 * j))) return r;  // rows(j) wait for everything enqueued so far (solve(j-1))
-        if ((r = launch_diag(j, j > 0 ? 1 : 0))) return r;
+        // rows(j) on the panel stream and the look-ahead bulk of step j+1 (rows <= j-1 are final) both start once
+        // solve(j-1) has retired.  Event form: ONE event recorded after solve(j-1) (every record between two kernels of
+        // the caller's stream costs ~3-7 us there).  Device form (dev_wait): nothing on the caller's stream at all —
+        // diag_kernel(j) publishes its start in sync[3] and a one-lane gate kernel heads the helper streams' work.
+        const bool bulk_next = lookahead(j + 1);
+        const bool rows_off_stream = has_rows && ps != s;
+        if (dev_gate && j == 0) {  // the helper streams' gates must not read sync before the prologue has zeroed it
+            BARK_HIP_CHECK(hipEventRecord(res->events[5], s));
+            BARK_HIP_CHECK(hipStreamWaitEvent(ps, res->events[5], 0));
+            BARK_HIP_CHECK(hipStreamWaitEvent(la_stream, res->events[5], 0));
+            BARK_HIP_CHECK(hipStreamWaitEvent(la_stream2, res->events[5], 0));
+        }
+        if (!dev_gate && (rows_off_stream || bulk_next)) BARK_HIP_CHECK(hipEventRecord(res->events[6 * j], s));
+        if (rows_off_stream) {
+            if (dev_gate) {
+                if ((r = gate(ps, j + 1))) return r;
+            } else {
+                BARK_HIP_CHECK(hipStreamWaitEvent(ps, res->events[6 * j], 0));
+            }
+        }
+        if (bulk_next) {
+            const int j2 = j + 1, S2 = split_factor(j2, j2 - 1, la_slots(j2));
+            // bulk-bound steps alternate between two streams, so that a bulk does not queue behind the last workgroups
+            // of its predecessor (one N = 16384 matrix 28.7 -> 28.1 ms, with 10^4 candidates 73.5 -> 69.3); in
+            // critical-path-bound steps two resident bulks would only take slots from the critical path
+            // (N = 4096, B = 8: 5.04 -> 5.26 ms)
+            hipStream_t ls = ((j2 & 1) && la_slots(j2) == LA_SLOTS) ? la_stream2 : la_stream;
+            if (dev_gate) {
+                if ((r = gate(ls, j + 1))) return r;
+            } else {
+                BARK_HIP_CHECK(hipStreamWaitEvent(ls, res->events[6 * j], 0));
+            }
+            if ((r = launch_split(ls, j2, 0, j2 - 1, S2, 0, S2 + 1))) return r;
+            BARK_HIP_CHECK(hipEventRecord(res->events[6 * j2 + 2], ls));
+        }
+        const bool wait_in_diag = dev_wait && rows_off_stream;
+        if ((r = launch_diag(j, j > 0 ? 1 : 0, 0, wait_in_diag ? 0 : (dev_wait ? -1 : -2), j + 1))) return r;
         if (has_rows) {
             if (timed) panel_marks.push_back(ev.size());
             if ((r = mark_on(ps))) return r;
@@ -1647,7 +1763,11 @@ struct Sweep {
                 }
             }
             if ((r = mark_on(ps))) return r;
-            if ((r = join(6 * j + 1))) return r;  // solve(j) (and diag(j+1)) need the row's tiles
+            if (wait_in_diag) {  // diag_kernel(j) waits for this counter before it ends: solve(j) follows it back to back
+                if ((r = publish(ps, 0, j + 1))) return r;
+            } else if ((r = join(6 * j + 1))) {  // solve(j) (and diag(j+1)) need the row's tiles
+                return r;
+            }
         }
         if (n_right > 0) {
             if (timed) solve_marks.push_back(ev.size());
@@ -1663,18 +1783,6 @@ struct Sweep {
             if ((r = mark_on(s))) return r;
             // 18 of the 32 (k-tile, row-tile) products per wave are executed (zero k-tiles of W_j skipped)
             solve_flops += (18.0 / 32.0) * 2.0 * NB * NB * (double)NB * (double)n_right * (double)bc;
-        }
-        if (lookahead(j + 2)) {  // rows <= j are final: the bulk of step j+2 can start now
-            const int j2 = j + 2, S2 = split_factor(j2, j2 - 1, la_slots(j2));
-            BARK_HIP_CHECK(hipEventRecord(res->events[6 * j + 3], s));
-            // bulk-bound steps alternate between two streams, so that a bulk does not queue behind the last workgroups
-            // of its predecessor (one N = 16384 matrix 28.7 -> 28.1 ms, with 10^4 candidates 73.5 -> 69.3); in
-            // critical-path-bound steps two resident bulks would only take slots from the critical path
-            // (N = 4096, B = 8: 5.04 -> 5.26 ms)
-            hipStream_t ls = ((j2 & 1) && la_slots(j2) == LA_SLOTS) ? la_stream2 : la_stream;
-            BARK_HIP_CHECK(hipStreamWaitEvent(ls, res->events[6 * j + 3], 0));
-            if ((r = launch_split(ls, j2, 0, j2 - 1, S2, 0, S2 + 1))) return r;
-            BARK_HIP_CHECK(hipEventRecord(res->events[6 * j2 + 2], ls));
         }
         return BARK_OK;
     }
@@ -1696,8 +1804,12 @@ struct Sweep {
         if (!has_bulk(j)) return BARK_OK;
         hipStream_t st = (j & 1) ? la_stream : panel;  // one bulk stream only: B = 256 at N = 4096 94 -> 100 ms
         int r;
-        BARK_HIP_CHECK(hipEventRecord(res->events[6 * j + 3], main));
-        BARK_HIP_CHECK(hipStreamWaitEvent(st, res->events[6 * j + 3], 0));
+        if (dev_gate && j >= 2) {  // called right after solve(j-2): diag_kernel(j-1), next on `main`, publishes j when it starts
+            if ((r = gate(st, j))) return r;
+        } else {
+            BARK_HIP_CHECK(hipEventRecord(res->events[6 * j + 3], main));
+            BARK_HIP_CHECK(hipStreamWaitEvent(st, res->events[6 * j + 3], 0));
+        }
         if (timed) panel_marks.push_back(ev.size());
         if ((r = mark_on(st))) return r;
         // the last block rows have few tiles and the longest K: below half a round of workgroups the launch splits K
@@ -1718,6 +1830,7 @@ struct Sweep {
             return r;
         }
         if ((r = mark_on(st))) return r;
+        if (dev_wait) return publish(st, j & 1, j + 1);  // diag_kernel(j) waits for the counter of this bulk stream
         BARK_HIP_CHECK(hipEventRecord(res->events[6 * j + 2], st));
         return BARK_OK;
     }
@@ -1729,13 +1842,22 @@ struct Sweep {
         const int bc = p.Bc, n_right = ncb - j - 1;
         int r;
         if (j == 0) {
+            if (dev_gate) {  // the bulk streams' gates must not read sync before the prologue has zeroed it
+                BARK_HIP_CHECK(hipEventRecord(res->events[5], main));
+                BARK_HIP_CHECK(hipStreamWaitEvent(panel, res->events[5], 0));
+                BARK_HIP_CHECK(hipStreamWaitEvent(la_stream, res->events[5], 0));
+            }
             if ((r = launch_bulk(0))) return r;
             if ((r = launch_bulk(1))) return r;
         }
         // the stored P_jj comes from the row launch of block row j-1: block rows kdone(j-1) .. j-1 are still to apply
         const bool deferred = j > kdone(j);
-        if ((r = launch_diag(j, j > 0 ? j - kdone(j - 1) : 0, deferred && n_right > 0))) return r;
-        if (has_bulk(j)) BARK_HIP_CHECK(hipStreamWaitEvent(main, res->events[6 * j + 2], 0));
+        // solve(j) (and the next diag) need bulk(j): awaited by event, or — few matrices — inside diag_kernel(j)
+        const bool wait_in_diag = dev_wait && has_bulk(j);
+        if ((r = launch_diag(j, j > 0 ? j - kdone(j - 1) : 0, deferred && n_right > 0, wait_in_diag ? (j & 1) : (dev_wait ? -1 : -2),
+                             j + 1)))
+            return r;
+        if (has_bulk(j) && !wait_in_diag) BARK_HIP_CHECK(hipStreamWaitEvent(main, res->events[6 * j + 2], 0));
         if (n_right > 0) {
             if (timed) solve_marks.push_back(ev.size());
             if ((r = mark_on(main))) return r;
@@ -1801,7 +1923,19 @@ struct Sweep {
 
 using namespace bark;
 
+namespace bark {
+std::atomic<bool> &device_wait_enabled() {
+    static std::atomic<bool> on{std::getenv("BARK_NO_DEVICE_WAIT") == nullptr};
+    return on;
+}
+}  // namespace bark
+
 extern "C" {
+
+int bark_device_wait(int on) {
+    const bool prev = device_wait_enabled().exchange(on != 0);
+    return prev ? 1 : 0;
+}
 
 size_t bark_mll_workspace_bytes(int64_t N, int64_t C, int64_t m, int64_t Bc) {
     if (N < 1 || C < 0 || m < 1 || Bc < 1) return 0;
@@ -1882,6 +2016,7 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
         p.W = reinterpret_cast<double *>(ws + L.off_W);
         p.yz = reinterpret_cast<double *>(ws + L.off_yz);
         p.accum = reinterpret_cast<double *>(ws + L.off_acc);
+        p.sync = reinterpret_cast<int32_t *>(ws + L.off_sync);
         p.nrb = nrb;
         p.ncb = ncb;
         p.nW = words;
@@ -1922,7 +2057,7 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
             if (r) return r;
         }
         dim3 g((unsigned)((L.npad + 255) / 256), (unsigned)bc);
-        hipLaunchKernelGGL(init_rhs_kernel, g, dim3(256), 0, s, y, (int)N, (int)L.npad, p.yz, p.accum, p.info);
+        hipLaunchKernelGGL(init_rhs_kernel, g, dim3(256), 0, s, y, (int)N, (int)L.npad, p.yz, p.accum, p.info, p.sync);
         BARK_LAUNCH_CHECK();
         return sw.mark_on(s);
     };
@@ -1931,7 +2066,7 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
         Mats &p = sw.p;
         hipStream_t s = sw.main;
         hipLaunchKernelGGL(finish_mll_kernel, dim3((unsigned)((bc + 255) / 256)), dim3(256), 0, s, p.accum, (int)bc, (int)N,
-                           (flags & BARK_MLL_INCLUDE_2PI) ? 1 : 0, mll_out + c0, ctx->fault, p.info);
+                           (flags & BARK_MLL_INCLUDE_2PI) ? 1 : 0, mll_out + c0, ctx->fault, p.info, sw.dev_wait ? p.sync : nullptr);
         BARK_LAUNCH_CHECK();
         if (C > 0) {
             const int prc = launch_predict_reduce(p, (int)N, (int)C, (int)bc, rhs_identity ? nullptr : scale + c0,
@@ -1949,11 +2084,24 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
         return BARK_OK;
     };
 
+    // device-side waits need the helper streams to run BESIDE the caller's stream: not under stream capture (a graph's
+    // branches may be replayed in any order) and not when switched off (bark_device_wait)
+    bool dev_wait_ok = device_wait_enabled().load();
+    if (dev_wait_ok) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        BARK_HIP_CHECK(hipStreamIsCapturing(caller, &cap));
+        dev_wait_ok = cap == hipStreamCaptureStatusNone;
+    }
     const size_t t_begin = sw.ev.size();
     if ((rc = sw.mark_on(caller))) return rc;
     for (int64_t c0 = 0; c0 < B; c0 += Bc) {  // chunks of Bc resident matrices, one after the other
         const int64_t bc = (B - c0 < Bc) ? (B - c0) : Bc;
         sw.pipelined = pipeline_ok && ((bc % 256) != 0 || nrb <= 16);
+        sw.dev_wait = dev_wait_ok && (splitk || sw.pipelined) && bc <= DEVWAIT_MAX_BC;
+        // gate kernels in place of the event record that releases the row streams: measured (one process per variant,
+        // gates | end-of-diag wait only | events, ms): pipelined N = 4096 x 8 4.44 | 4.59 | 4.64, N = 8192 x 2 8.18 | 8.35 |
+        // 8.48; split-K layout N = 4096 x 1 2.19 | 2.14 | 2.22, N = 1024 x 1 0.575 | 0.520 | 0.534 — pipelined only
+        sw.dev_gate = sw.dev_wait && sw.pipelined;
         if ((rc = prologue(c0, bc))) return rc;
         for (int j = 0; j < nrb; ++j)
             if ((rc = sw.step(j))) return rc;
@@ -2070,6 +2218,7 @@ static int leafspace_run(bark_ctx *ctx, const void *packed, const bark_pack_info
     p.W = reinterpret_cast<double *>(ws + g.L.off_W);
     p.yz = reinterpret_cast<double *>(ws + g.L.off_yz);
     p.accum = reinterpret_cast<double *>(ws + g.L.off_acc);
+    p.sync = nullptr;  // R x R systems: a block row or two, event joins are fine (sw.dev_wait stays false)
     p.nrb = nrb;
     p.ncb = ncb;
     p.leafx = nullptr;

@@ -117,21 +117,35 @@ def _run(forest, noise, scale, X, y, feat_types, flags, cand=None, timing=None, 
     out = torch.empty(B, dtype=torch.float64, device=Xd.device)
     info = torch.empty(B, dtype=torch.int32, device=Xd.device)
     tref = ctypes.byref(timing) if timing is not None else None
-    _lib.check(lib.bark_mll_batched_hip(
-        _lib.ctx(), _lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(yd), _lib.ptr(noise_d), _lib.ptr(scale_d),
-        _lib.ptr(shift_d), flags, _lib.ptr(cand_d), C, _lib.ptr(out), _lib.ptr(mu), _lib.ptr(var), _lib.ptr(cov),
-        _lib.ptr(info),
-        _lib.ptr(ws), ws.numel(), Bc, tref, _lib.stream_ptr()))
-    _raise_on_info(info, "kernel matrix")
+    def call():
+        _lib.check(lib.bark_mll_batched_hip(
+            _lib.ctx(), _lib.ptr(pf.packed), pf.info_ref, _lib.ptr(Xd), N, d, _lib.ptr(yd), _lib.ptr(noise_d), _lib.ptr(scale_d),
+            _lib.ptr(shift_d), flags, _lib.ptr(cand_d), C, _lib.ptr(out), _lib.ptr(mu), _lib.ptr(var), _lib.ptr(cov),
+            _lib.ptr(info),
+            _lib.ptr(ws), ws.numel(), Bc, tref, _lib.stream_ptr()))
+
+    call()
+    bad = info.cpu().numpy()  # the one read-back of the call's status
+    if (bad == -3).any():
+        # the helper streams did not run beside this one (include/bark_hip.h, bark_device_wait): event joins from now on
+        import warnings
+
+        warnings.warn("bark_amd: device-side wait timed out; falling back to event joins for this process", RuntimeWarning)
+        lib.bark_device_wait(0)
+        call()
+        bad = info.cpu().numpy()
+    _raise_on_info(bad, "kernel matrix")
     return (out, mu, var, cov) if want_cov else (out, mu, var)
 
 
 def _raise_on_info(info, what: str):
     """info_out of the sweep entry points: -1 = invalid categorical value met by a leaf walk (ValueError, as the
     reference's `1 << int(x)`), k > 0 = first non-positive pivot (LinAlgError, as np.linalg.inv on a singular matrix)."""
-    bad = info.cpu().numpy()
+    bad = info if isinstance(info, np.ndarray) else info.cpu().numpy()
     if not bad.any():
         return
+    if (bad == -3).any():
+        raise RuntimeError("bark_hip: a device-side wait timed out (bark_device_wait / $BARK_NO_DEVICE_WAIT)")
     if (bad < 0).any():
         _clear_fault()  # read-and-reset, so the next call starts clean
         raise ValueError("categorical feature value is negative, NaN or inf")

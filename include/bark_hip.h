@@ -54,6 +54,14 @@ enum {
 int bark_version(void);
 /* Last error message of the calling thread ("" if none).  Pointer valid until the next call. */
 const char *bark_last_error(void);
+/* Process-wide switch (returns the previous setting; default on, off when $BARK_NO_DEVICE_WAIT is set).  On: sweeps of
+ * few resident matrices — bound by the dependent chain diag -> solve -> diag (bark_sampler.py:153-162 with one chain,
+ * BASELINE configs c2 / c5) — hand the completion of their row launches over to the caller's stream through a
+ * device-side progress counter that the diagonal-block kernel waits for (bounded: 2 s), instead of a cross-stream
+ * event wait between two kernels of that stream.  It needs the library's helper streams to run beside the caller's;
+ * where they cannot (every stream of the process serialised onto one hardware queue), the wait times out and the call
+ * reports info_out[b] = -3: switch it off and call again.  Never used under stream capture. */
+int bark_device_wait(int on);
 
 /* ---------------------------------------------------------------------------------------
  * Context — replaces nothing in the reference (pure functions on numpy arrays, forest.py:58-111); it is where the
@@ -165,7 +173,8 @@ int bark_gram_from_leaves_hip(const uint32_t *leaf1, int64_t N, const uint32_t *
  *
  * workspace: device buffer of at least bark_mll_workspace_bytes(N, C, m, Bc) bytes, where Bc
  * (1 <= Bc <= B) is the number of forests resident / factorised concurrently; B is processed in chunks of Bc.
- * info_out (device, B int32): 0, or 1-based index of the first non-positive pivot (not PD), or -1 when a leaf walk
+ * info_out (device, B int32): 0, or 1-based index of the first non-positive pivot (not PD), or -3 when a device-side
+ *   wait timed out (bark_device_wait), or -1 when a leaf walk
  * of the call met an invalid categorical value (see bark_ctx_status).
  * ------------------------------------------------------------------------------------- */
 size_t bark_mll_workspace_bytes(int64_t N, int64_t C, int64_t m, int64_t Bc);

@@ -88,6 +88,28 @@ def test_two_host_threads_on_two_streams(env):
             assert np.array_equal(out, serial[k])
 
 
+def test_device_side_wait_and_event_joins_give_identical_bits(env):
+    """Sweeps of few matrices hand row-launch completion to the caller's stream through a device-side counter that
+    diag_kernel waits for (include/bark_hip.h, bark_device_wait); switched off, the same kernels are ordered by events.
+    Same arithmetic either way: identical bits — on the split-K layout (lone matrix, look-ahead) and on the pipelined
+    schedule (gate kernels on the row streams) — and no timed-out wait (info == 0)."""
+    import bench
+
+    lib = env.lib.lib()
+    for N, Bn in ((1500, 1), (6900, 1), (2100, 6), (1100, 24)):
+        wl = bench.Workload(N, 8, 50, Bn, seed_base=N, rank_offset=0)
+        assert lib.bark_device_wait(1) in (0, 1)
+        wl.run()
+        env.torch.cuda.synchronize()
+        on = wl.mll_d.clone()
+        assert int(wl.info_d.abs().max().item()) == 0
+        assert lib.bark_device_wait(0) == 1
+        wl.run()
+        env.torch.cuda.synchronize()
+        assert lib.bark_device_wait(1) == 0
+        assert bool((wl.mll_d == on).all()) and int(wl.info_d.abs().max().item()) == 0
+
+
 def test_sweep_is_hipgraph_capturable(env):
     """The ABI's claim: `*_hip` entry points only enqueue work (fork/join of the helper stream included), so a call can
     be captured into a graph and replayed — what a latency-bound caller (one small matrix) wants."""
