@@ -499,15 +499,47 @@ struct UpperBlocks<3> {
 
 constexpr int UPD_STAGE = BK * LDS_LD;  // one operand: 16 rows x (128 + 16) doubles
 
+// Matrices of ONE block row (N <= 128: where BARK itself lives — BO with tens of points, BASELINE configs[0] is N = 64):
+// diag_kernel does the whole evaluation in one launch.  It generates its tile from the leaf codes (as form_tile does),
+// takes y straight from the caller, and writes the MLL (finish_mll_kernel's arithmetic) — no Gram fill, no right-hand-side
+// initialisation, no finishing launch (5 launches -> walk + this one).
+struct OneBlock {
+    const double *y;       // (N,) targets, or nullptr: the regular multi-block sweep
+    double *mll;           // (Bc,) result
+    const int32_t *fault;  // the context's categorical-fault flag (set by the leaf walk that precedes this launch)
+    int include_2pi, rep;  // MLL convention; leaf-code encoding (LeafRep)
+};
+
+__device__ __forceinline__ uint32_t code_count_rt(int rep, uint32_t a, uint32_t b) {
+    return rep == REP_BITS ? code_count<REP_BITS>(a, b) : rep == REP_BYTES7 ? code_count<REP_BYTES7>(a, b) : code_count<REP_BYTES8>(a, b);
+}
+// A[gi][gj] of matrix b from the leaf codes staged in LDS (codes[w][128]): form_tile's arithmetic, operation for operation
+__device__ __forceinline__ double gen_entry(const Mats &p, int b, int rep, const uint32_t *codes, int gi, int gj) {
+    if (gi >= p.N || gj >= p.N) return gi == gj ? 1.0 : 0.0;  // identity padding
+    uint32_t cnt = 0;
+    for (int w = 0; w < p.nW; ++w) cnt += code_count_rt(rep, codes[w * NB + gi], codes[w * NB + gj]);
+    const int agree = rep == REP_BITS ? (int)cnt : p.m - (int)cnt;
+    double val = (1.0 / (double)p.m) * (double)agree;
+    if (p.shift) val = val - p.shift[b];
+    if (p.scale) val = p.scale[b] * val;
+    if (gi == gj) val = val + (1e-6 + p.noise[b]);
+    return val;
+}
+
+// codes != nullptr (one-block-row sweeps): the tile is generated from the leaf codes in LDS instead of read from `tile`.
 template <int W>
 __device__ __forceinline__ void diag_update(const double *__restrict__ tile, long ld, const double *__restrict__ panel0,
-                                            int nkb, double *lds, double *S, int lane, int lr, int lk) {
+                                            int nkb, double *lds, double *S, int lane, int lr, int lk, const Mats &p, int b,
+                                            int rep, const uint32_t *codes) {
     using T = UpperBlocks<W>;
     double pre[9][4];
 #pragma unroll
     for (int i = 0; i < 9; ++i)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) pre[i][v] = tile[(size_t)(T::rb[i] * 16 + lk + 4 * v) * ld + T::cb[i] * 16 + lr];
+        for (int v = 0; v < 4; ++v) {
+            const int r = T::rb[i] * 16 + lk + 4 * v, c = T::cb[i] * 16 + lr;
+            pre[i][v] = codes ? gen_entry(p, b, rep, codes, r, c) : tile[(size_t)r * ld + c];
+        }
     f64x4 acc[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
@@ -601,7 +633,8 @@ __device__ __forceinline__ void diag_g(const double *__restrict__ Up, long ld, c
 // cross-stream event wait costs ~5-13 us there, kernels back to back 0.8 us (tools/gap_probe.hip), and the row launch
 // is normally long done.  Only this kernel spins — at most 32 workgroups, on CUs the row kernels do not need — and what
 // it waits for never waits for it (the row launch was released by an event recorded before this kernel was enqueued).
-__global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb, int want_g, int wait_slot, int wait_value) {
+// ob.y != nullptr: the one-launch evaluation of matrices of one block row (OneBlock; j == 0, nkb == 0).
+__global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb, int want_g, int wait_slot, int wait_value, OneBlock ob) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, b = blockIdx.x;
     const Lane q = lane_of(tid);
@@ -612,28 +645,36 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
     // (solve_kernel(j-1) finished updating y_j before this launch)
     if (wait_slot >= -1 && b == 0 && tid == 0 && p.sync)  // this launch has started: everything before it on this stream is done
         __hip_atomic_store(p.sync + 3, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const double y_in = tid < NB ? p.yz[(size_t)b * p.nrb * NB + (size_t)j * NB + tid] : 0.0;
-    const double acc_quad = tid == 0 ? p.accum[(size_t)b * 2 + 0] : 0.0;
-    const double acc_logdet = tid == 0 ? p.accum[(size_t)b * 2 + 1] : 0.0;
-    const int info_in = tid == 0 ? p.info[b] : 0;
+    const bool one = ob.y != nullptr;  // workgroup-uniform
+    const double y_in = tid < NB ? (one ? (tid < p.N ? ob.y[tid] : 0.0) : p.yz[(size_t)b * p.nrb * NB + (size_t)j * NB + tid]) : 0.0;
+    const double acc_quad = (tid == 0 && !one) ? p.accum[(size_t)b * 2 + 0] : 0.0;
+    const double acc_logdet = (tid == 0 && !one) ? p.accum[(size_t)b * 2 + 1] : 0.0;
+    const int info_in = (tid == 0 && !one) ? p.info[b] : 0;
 
     double *S = lds;                                          // packed upper block triangle, NBLK x [16][16]
     double *scratch = lds + NBLK * SB * SB + wave * SB * TS;  // per-wave [16][TS]
     double *vec = lds + NBLK * SB * SB + 4 * SB * TS;         // [2][128] y | upper-half partial sums
     double *red = vec + 2 * NB;                               // [8]
+    uint32_t *codes = nullptr;
+    if (one) {  // the matrix's leaf codes (nW x 128 dwords) behind everything else in LDS
+        codes = reinterpret_cast<uint32_t *>(red + 8);
+        const uint32_t *lb = p.leafx + (size_t)b * p.nW * NB;  // npad == 128
+        for (int e = tid; e < p.nW * NB; e += THREADS) codes[e] = lb[e];
+        __syncthreads();
+    }
     {
         // D = P - sum_k U[k,j]'U[k,j] on the upper block triangle (the product stages alias S: the update's last barrier
         // precedes the writes of S)
         const double *prev = Ab + (size_t)(j - nkb) * NB * p.ld + (size_t)j * NB;  // U[j-nkb, j]
         const int wsel = __builtin_amdgcn_readfirstlane(wave);
         if (wsel == 0)
-            diag_update<0>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk);
+            diag_update<0>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk, p, b, ob.rep, codes);
         else if (wsel == 1)
-            diag_update<1>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk);
+            diag_update<1>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk, p, b, ob.rep, codes);
         else if (wsel == 2)
-            diag_update<2>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk);
+            diag_update<2>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk, p, b, ob.rep, codes);
         else
-            diag_update<3>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk);
+            diag_update<3>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk, p, b, ob.rep, codes);
     }
     __syncthreads();
 
@@ -659,9 +700,12 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
     f64x4 pend[3];  // column kb of X for the owned rows, stored at the start of the next step
     if (wave_u == 0) factor16(S + blk_off(0, 0), lane, 0, logsum, bad);
     __syncthreads();
-    for (int kb = 0; kb < NSB; ++kb) {
+    // one-block-row matrices of fewer than 113 points: the sub-blocks beyond the last live one are identity padding — their
+    // factor, their inverse and their share of log|D| are what the tile generation left there, nothing to compute
+    const int nsb = one ? (p.N + SB - 1) / SB : NSB;
+    for (int kb = 0; kb < nsb; ++kb) {
         double *dblk = S + blk_off(kb, kb);  // W_kk
-        for (int cb = kb + 1 + wave_u; cb < NSB; cb += 4) {  // (B)
+        for (int cb = kb + 1 + wave_u; cb < nsb; cb += 4) {  // (B)
             double *blk = S + blk_off(kb, cb);
             f64x4 u = {0.0, 0.0, 0.0, 0.0};
             mfma_tn(u, dblk, SB, blk, SB, lr, lk);
@@ -670,7 +714,7 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
         }
         __syncthreads();
         if (wave_u == 0) {
-            if (kb + 1 < NSB) {
+            if (kb + 1 < nsb) {
                 const double *urow = S + blk_off(kb, kb + 1);
                 double *dst = S + blk_off(kb + 1, kb + 1);
                 f64x4 u = {0.0, 0.0, 0.0, 0.0};
@@ -694,8 +738,8 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
                 __builtin_amdgcn_wave_barrier();
             }
             int pair = 0;
-            for (int rb = kb + 1; rb < NSB; ++rb)  // (C), all but the next diagonal sub-block
-                for (int cb = rb; cb < NSB; ++cb) {
+            for (int rb = kb + 1; rb < nsb; ++rb)  // (C), all but the next diagonal sub-block
+                for (int cb = rb; cb < nsb; ++cb) {
                     if (rb == kb + 1 && cb == kb + 1) continue;
                     if (pair++ % 3 + 1 != wave_u) continue;
                     f64x4 u = {0.0, 0.0, 0.0, 0.0};
@@ -727,8 +771,8 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
     if (wave_u != 0) {  // last column of X
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            if (xrow[i] >= 0 && xrow[i] < NSB - 1) {
-                double *dst = S + blk_off(xrow[i], NSB - 1);
+            if (xrow[i] >= 0 && xrow[i] < nsb - 1) {
+                double *dst = S + blk_off(xrow[i], nsb - 1);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) dst[(lk + 4 * v) * SB + lr] = pend[i][v];
             }
@@ -738,7 +782,7 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
     // --- W_j out, sub-block by sub-block (explicit zeros below the block diagonal: solve_kernel multiplies the full
     // tile; the diagonal sub-blocks are upper triangular with exact zeros already) --------------------------------
     double *Wb = w_block(p, b);
-    {
+    if (!one) {  // (nobody reads W_0 of a one-block-row matrix)
         const int r = tid >> 4, c = tid & 15;  // one element of every 16 x 16 sub-block per thread
 #pragma unroll
         for (int rbk = 0; rbk < NSB; ++rbk)
@@ -773,7 +817,7 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
         double zz = 0.0;
         if (!half) {
             const double z = part + vec[NB + c];
-            yb[c] = z;
+            if (!one) yb[c] = z;
             zz = z * z;
         }
 #pragma unroll
@@ -781,7 +825,12 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
         if (lane == 0) red[wave] = zz;
     }
     __syncthreads();
-    if (tid == 0) {  // wave 0 ran factor16: its logsum / bad are the matrix's
+    if (tid == 0 && one) {  // finish_mll_kernel's arithmetic (quick_inverse.py:38 / mcmc_record_mll.py:73)
+        double v = -(red[0] + red[1]) - 2.0 * logsum;
+        if (ob.include_2pi) v = v - (double)p.N * log(2.0 * M_PI);
+        ob.mll[b] = 0.5 * v;
+        p.info[b] = *ob.fault ? -1 : (bad ? bad : 0);
+    } else if (tid == 0) {  // wave 0 ran factor16: its logsum / bad are the matrix's
         p.accum[(size_t)b * 2 + 0] = acc_quad + (red[0] + red[1]);
         p.accum[(size_t)b * 2 + 1] = acc_logdet + 2.0 * logsum;
         int code = (bad && info_in == 0) ? j * NB + bad : 0;
@@ -1576,6 +1625,15 @@ struct Sweep {
     }
 
     // wait_slot: -2 no device-side hand-over; -1 publish the start only; 0 / 1: also wait for that row stream at the end
+    // the whole evaluation of a chunk of one-block-row matrices (N <= 128) in one launch: see OneBlock
+    int launch_one_block(const double *y, double *mll, const int32_t *fault, int include_2pi) {
+        const OneBlock ob{y, mll, fault, include_2pi, rep};
+        const size_t lds_bytes = DIAG_LDS + (size_t)p.nW * NB * sizeof(uint32_t);
+        hipLaunchKernelGGL(diag_kernel, dim3((unsigned)p.Bc), dim3(THREADS), lds_bytes, main, p, 0, 0, 0, -2, 0, ob);
+        BARK_LAUNCH_CHECK();
+        return BARK_OK;
+    }
+
     int launch_diag(int j, int nkb, int want_g = 0, int wait_slot = -2, int wait_value = 0) {
         int r;
         if (timed) diag_marks.push_back(ev.size());
@@ -1586,7 +1644,7 @@ struct Sweep {
         // pipelined schedule's row launches retire workgroups continuously: there the whole-CU request stays the
         // better choice — one N = 16384 matrix 26.6 against 28.3 ms, N = 4096 x 8 4.87 against 5.34.)
         const bool exclusive = p.Bc <= DIAG_EXCLUSIVE_MAX_BC && !lookahead(j + 1);
-        hipLaunchKernelGGL(diag_kernel, dim3((unsigned)p.Bc), dim3(THREADS), exclusive ? DIAG_LDS_EXCLUSIVE : DIAG_LDS, main, p, j, nkb, want_g, wait_slot, wait_value);
+        hipLaunchKernelGGL(diag_kernel, dim3((unsigned)p.Bc), dim3(THREADS), exclusive ? DIAG_LDS_EXCLUSIVE : DIAG_LDS, main, p, j, nkb, want_g, wait_slot, wait_value, OneBlock{});
         BARK_LAUNCH_CHECK();
         return mark_on(main);
     }
@@ -2097,6 +2155,22 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
     for (int64_t c0 = 0; c0 < B; c0 += Bc) {  // chunks of Bc resident matrices, one after the other
         const int64_t bc = (B - c0 < Bc) ? (B - c0) : Bc;
         sw.pipelined = pipeline_ok && ((bc % 256) != 0 || nrb <= 16);
+        if (nrb == 1 && fused && C == 0 && !timing) {  // N <= 128: leaf walk + ONE launch per chunk (OneBlock)
+            Mats &p1 = sw.p;
+            bark_pack_info sub = *info;
+            sub.B = bc;
+            p1.info = info_out + c0;
+            p1.Bc = (int)bc;
+            p1.leafx = leafx;
+            p1.scale = use_scale ? scale + c0 : nullptr;
+            p1.shift = shift ? shift + c0 : nullptr;
+            p1.noise = noise + c0;
+            if ((rc = walk_codes(static_cast<const char *>(packed) + (size_t)c0 * m * info->stride * 16, &sub, X, N, d, leafx, ctx->fault,
+                                 caller)))
+                return rc;
+            if ((rc = sw.launch_one_block(y, mll_out + c0, ctx->fault, (flags & BARK_MLL_INCLUDE_2PI) ? 1 : 0))) return rc;
+            continue;
+        }
         sw.dev_wait = dev_wait_ok && (splitk || sw.pipelined) && bc <= DEVWAIT_MAX_BC;
         // gate kernels in place of the event record that releases the row streams: measured (one process per variant,
         // gates | end-of-diag wait only | events, ms): pipelined N = 4096 x 8 4.44 | 4.59 | 4.64, N = 8192 x 2 8.18 | 8.35 |

@@ -11,7 +11,9 @@ MLL_RTOL, MLL_ATOL = 1e-9, 1e-8
 
 # (N, B, m, C, chunk) — N not a multiple of 128, batch sizes around the schedule thresholds
 CASES = [
-    (1, 1, 3, 0, None), (2, 5, 1, 0, None), (130, 300, 7, 0, None), (257, 64, 50, 0, None), (513, 48, 20, 0, 16),
+    (1, 1, 3, 0, None), (2, 5, 1, 0, None), (130, 300, 7, 0, None),
+    # one block row (N <= 128): the single-launch evaluation (chol.hip OneBlock), incl. chunks and the full 128
+    (64, 256, 50, 0, None), (100, 7, 13, 0, None), (128, 40, 50, 0, 16), (20, 3, 50, 0, None), (257, 64, 50, 0, None), (513, 48, 20, 0, 16),
     (700, 100, 13, 0, None), (777, 33, 50, 0, None), (900, 12, 50, 0, None), (1100, 64, 50, 0, None),
     (1300, 40, 30, 0, 24), (1500, 9, 50, 0, None), (2100, 2, 50, 0, None), (2500, 20, 50, 0, None),
     (640, 16, 50, 90, None), (1000, 70, 25, 130, None), (1400, 3, 50, 300, None),
