@@ -527,7 +527,7 @@ __device__ __forceinline__ double gen_entry(const Mats &p, int b, int rep, const
 }
 
 // codes != nullptr (one-block-row sweeps): the tile is generated from the leaf codes in LDS instead of read from `tile`.
-template <int W>
+template <int W, bool ONE>
 __device__ __forceinline__ void diag_update(const double *__restrict__ tile, long ld, const double *__restrict__ panel0,
                                             int nkb, double *lds, double *S, int lane, int lr, int lk, const Mats &p, int b,
                                             int rep, const uint32_t *codes) {
@@ -538,7 +538,7 @@ __device__ __forceinline__ void diag_update(const double *__restrict__ tile, lon
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int r = T::rb[i] * 16 + lk + 4 * v, c = T::cb[i] * 16 + lr;
-            pre[i][v] = codes ? gen_entry(p, b, rep, codes, r, c) : tile[(size_t)r * ld + c];
+            pre[i][v] = ONE ? gen_entry(p, b, rep, codes, r, c) : tile[(size_t)r * ld + c];
         }
     f64x4 acc[9];
 #pragma unroll
@@ -633,7 +633,9 @@ __device__ __forceinline__ void diag_g(const double *__restrict__ Up, long ld, c
 // cross-stream event wait costs ~5-13 us there, kernels back to back 0.8 us (tools/gap_probe.hip), and the row launch
 // is normally long done.  Only this kernel spins — at most 32 workgroups, on CUs the row kernels do not need — and what
 // it waits for never waits for it (the row launch was released by an event recorded before this kernel was enqueued).
-// ob.y != nullptr: the one-launch evaluation of matrices of one block row (OneBlock; j == 0, nkb == 0).
+// ONE: the one-launch evaluation of matrices of one block row (OneBlock; j == 0, nkb == 0) — an instantiation of its
+// own, so that the regular kernel carries none of its code (with a run-time switch diag_kernel ran 52 -> 60 us).
+template <bool ONE>
 __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb, int want_g, int wait_slot, int wait_value, OneBlock ob) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, b = blockIdx.x;
@@ -645,7 +647,7 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
     // (solve_kernel(j-1) finished updating y_j before this launch)
     if (wait_slot >= -1 && b == 0 && tid == 0 && p.sync)  // this launch has started: everything before it on this stream is done
         __hip_atomic_store(p.sync + 3, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool one = ob.y != nullptr;  // workgroup-uniform
+    constexpr bool one = ONE;
     const double y_in = tid < NB ? (one ? (tid < p.N ? ob.y[tid] : 0.0) : p.yz[(size_t)b * p.nrb * NB + (size_t)j * NB + tid]) : 0.0;
     const double acc_quad = (tid == 0 && !one) ? p.accum[(size_t)b * 2 + 0] : 0.0;
     const double acc_logdet = (tid == 0 && !one) ? p.accum[(size_t)b * 2 + 1] : 0.0;
@@ -668,13 +670,13 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
         const double *prev = Ab + (size_t)(j - nkb) * NB * p.ld + (size_t)j * NB;  // U[j-nkb, j]
         const int wsel = __builtin_amdgcn_readfirstlane(wave);
         if (wsel == 0)
-            diag_update<0>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk, p, b, ob.rep, codes);
+            diag_update<0, ONE>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk, p, b, ob.rep, codes);
         else if (wsel == 1)
-            diag_update<1>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk, p, b, ob.rep, codes);
+            diag_update<1, ONE>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk, p, b, ob.rep, codes);
         else if (wsel == 2)
-            diag_update<2>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk, p, b, ob.rep, codes);
+            diag_update<2, ONE>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk, p, b, ob.rep, codes);
         else
-            diag_update<3>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk, p, b, ob.rep, codes);
+            diag_update<3, ONE>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk, p, b, ob.rep, codes);
     }
     __syncthreads();
 
@@ -1539,7 +1541,8 @@ int set_lds_limits() {
         auto set = [](const void *fn, size_t bytes) {
             return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         };
-        hipError_t e = set(reinterpret_cast<const void *>(diag_kernel), DIAG_LDS_EXCLUSIVE);
+        hipError_t e = set(reinterpret_cast<const void *>(diag_kernel<false>), DIAG_LDS_EXCLUSIVE);
+        if (e == hipSuccess) e = set(reinterpret_cast<const void *>(diag_kernel<true>), DIAG_LDS_EXCLUSIVE);
         if (e == hipSuccess) e = set(reinterpret_cast<const void *>(row_kernel<0>), GEMM_LDS);
         if (e == hipSuccess) e = set(reinterpret_cast<const void *>(row_kernel<1>), GEMM_LDS);
         if (e == hipSuccess) e = set(reinterpret_cast<const void *>(row_kernel<2>), GEMM_LDS);
@@ -1629,7 +1632,7 @@ struct Sweep {
     int launch_one_block(const double *y, double *mll, const int32_t *fault, int include_2pi) {
         const OneBlock ob{y, mll, fault, include_2pi, rep};
         const size_t lds_bytes = DIAG_LDS + (size_t)p.nW * NB * sizeof(uint32_t);
-        hipLaunchKernelGGL(diag_kernel, dim3((unsigned)p.Bc), dim3(THREADS), lds_bytes, main, p, 0, 0, 0, -2, 0, ob);
+        hipLaunchKernelGGL(diag_kernel<true>, dim3((unsigned)p.Bc), dim3(THREADS), lds_bytes, main, p, 0, 0, 0, -2, 0, ob);
         BARK_LAUNCH_CHECK();
         return BARK_OK;
     }
@@ -1644,7 +1647,7 @@ struct Sweep {
         // pipelined schedule's row launches retire workgroups continuously: there the whole-CU request stays the
         // better choice — one N = 16384 matrix 26.6 against 28.3 ms, N = 4096 x 8 4.87 against 5.34.)
         const bool exclusive = p.Bc <= DIAG_EXCLUSIVE_MAX_BC && !lookahead(j + 1);
-        hipLaunchKernelGGL(diag_kernel, dim3((unsigned)p.Bc), dim3(THREADS), exclusive ? DIAG_LDS_EXCLUSIVE : DIAG_LDS, main, p, j, nkb, want_g, wait_slot, wait_value, OneBlock{});
+        hipLaunchKernelGGL(diag_kernel<false>, dim3((unsigned)p.Bc), dim3(THREADS), exclusive ? DIAG_LDS_EXCLUSIVE : DIAG_LDS, main, p, j, nkb, want_g, wait_slot, wait_value, OneBlock{});
         BARK_LAUNCH_CHECK();
         return mark_on(main);
     }

@@ -5,6 +5,9 @@
 ROOT=$(pwd)
 label=$1; N=${2:-4096}; B=${3:-256}; STEPS=${4:-1}
 export PYTHONPATH=$ROOT
+# counter collection serialises the dispatches: the device-side hand-over of chain-bound sweeps (bark_device_wait) would wait
+# for a row launch that cannot run beside diag_kernel — event joins for these passes
+export BARK_NO_DEVICE_WAIT=1
 mkdir -p $ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_sq_$label
