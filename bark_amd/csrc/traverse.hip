@@ -18,6 +18,7 @@ namespace bark {
 namespace {
 
 constexpr int WALK_THREADS = 256;
+constexpr int IDX_CHUNK = 32;  // leaf_walk_kernel MODE 0: trees per staged chunk (one 128-byte segment per point)
 
 template <bool X_IN_LDS>
 __device__ __forceinline__ uint4 walk_tree(const uint4 *__restrict__ tree, int max_depth, const double *xrow,
@@ -74,6 +75,27 @@ __global__ __launch_bounds__(WALK_THREADS) void leaf_walk_kernel(const uint4 *__
     const uint4 *forest = nodes + (size_t)b * m * stride;
 
     if (MODE == 0) {
+        // the reference's (N, m) layout: a thread's m results are one row, so threads would store m dwords apart.  The
+        // results go through LDS in chunks of IDX_CHUNK trees instead and leave as 128-byte row segments, 32 lanes a row
+        // (X_IN_LDS only: the staging tile sits behind the point rows; the fallback for very wide X stores directly)
+        if (X_IN_LDS) {
+            uint32_t *st = reinterpret_cast<uint32_t *>(xs + WALK_THREADS * sd);  // [256][IDX_CHUNK + 1]
+            const int row0 = blockIdx.x * WALK_THREADS, rows = min(WALK_THREADS, N - row0);
+            uint32_t *ob = out + ((size_t)b * N + row0) * m;
+            for (int t0 = 0; t0 < m; t0 += IDX_CHUNK) {
+                const int nt = min(IDX_CHUNK, m - t0);
+                if (live)
+                    for (int k = 0; k < nt; ++k)
+                        st[tid * (IDX_CHUNK + 1) + k] = walk_tree<true>(forest + (size_t)(t0 + k) * stride, max_depth, xrow, fault).y;
+                __syncthreads();
+                for (int e = tid; e < rows * IDX_CHUNK; e += WALK_THREADS) {
+                    const int r = e / IDX_CHUNK, k = e - r * IDX_CHUNK;
+                    if (k < nt) ob[(size_t)r * m + t0 + k] = st[r * (IDX_CHUNK + 1) + k];
+                }
+                __syncthreads();
+            }
+            return;
+        }
         if (!live) return;
         uint32_t *o = out + ((size_t)b * N + i) * m;
         for (int t = 0; t < m; ++t) o[t] = walk_tree<X_IN_LDS>(forest + (size_t)t * stride, max_depth, xrow, fault).y;
@@ -196,7 +218,8 @@ int launch_walk(const void *packed, const bark_pack_info *info, const double *X,
                     MAX_LEAF_WORDS);
     const int64_t extent = MODE != 0 ? npad : N;
     dim3 grid((unsigned)((extent + WALK_THREADS - 1) / WALK_THREADS), (unsigned)info->B);
-    const size_t lds = (size_t)WALK_THREADS * (d | 1) * sizeof(double);
+    const size_t lds = (size_t)WALK_THREADS * (d | 1) * sizeof(double) +
+                       (MODE == 0 ? (size_t)WALK_THREADS * (IDX_CHUNK + 1) * sizeof(uint32_t) : 0);  // + MODE 0's staging tile
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint4 *nodes = static_cast<const uint4 *>(packed);
     if constexpr (MODE != 0) {
