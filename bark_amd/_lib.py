@@ -47,6 +47,11 @@ SIGNATURES = {
     "bark_version": (ci, []),
     "bark_last_error": (ctypes.c_char_p, []),
     "bark_device_wait": (ci, [ci]),
+    "bark_comm_unique_id": (ci, [vp]),
+    "bark_comm_create": (ci, [vp, ci, ci, ci, ctypes.POINTER(vp)]),
+    "bark_comm_destroy": (None, [vp]),
+    "bark_allgather_mll": (ci, [vp, vp, i64, vp, vp]),
+    "bark_allreduce_f64": (ci, [vp, vp, i64, ci, vp]),
     "bark_forest_pack_info": (ci, [vp, i64, i64, i64, vp, i64, ctypes.POINTER(PackInfo)]),
     "bark_forest_pack": (ci, [vp, vp, i64, ctypes.POINTER(PackInfo), vp]),
     "bark_ctx_create": (ci, [ci, ctypes.POINTER(vp)]),

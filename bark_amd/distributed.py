@@ -79,3 +79,103 @@ def reduce_mixture(mu_local, var_local, total: int, group=None):
         return mean, var
     mean = partial[0] / total
     return mean, partial[1] / total - mean**2
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The same two exchanges through the C ABI (include/bark_hip.h: bark_comm_* / bark_allgather_mll / bark_allreduce_f64):
+# RCCL without torch.distributed.  Opt-in (`bench.py` with BARK_BENCH_BACKEND=abi); the default stays torch.distributed.
+# ----------------------------------------------------------------------------------------------------------------------
+def exchange_unique_id(rank: int, world: int, addr: str, port: int, make_id, timeout: float = 120.0) -> bytes:
+    """Rank 0 makes the 128-byte RCCL unique id (`make_id()`) and hands it to the other ranks over TCP (they connect to
+    addr:port, retrying until rank 0 listens).  Plain sockets: no process group is needed to build one."""
+    import socket
+    import time
+
+    if world == 1:
+        return make_id()
+    if rank == 0:
+        uid = make_id()
+        with socket.socket() as srv:
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            for _ in range(world - 1):
+                conn, _peer = srv.accept()
+                with conn:
+                    conn.sendall(uid)
+        return uid
+    deadline = time.monotonic() + timeout
+    while True:
+        try:
+            with socket.create_connection((addr, port), timeout=5.0) as c:
+                buf = b""
+                while len(buf) < 128:
+                    part = c.recv(128 - len(buf))
+                    if not part:
+                        raise ConnectionError("rank 0 closed the connection before the id was complete")
+                    buf += part
+                return buf
+        except (ConnectionRefusedError, ConnectionError, OSError):
+            if time.monotonic() > deadline:
+                raise
+            time.sleep(0.05)
+
+
+class RcclGroup:
+    """One RCCL communicator per process, built and used through the C ABI only (one process per GPU)."""
+
+    def __init__(self, rank: int, world: int, device: int, addr: str = "127.0.0.1", port: int = 29533):
+        import ctypes
+
+        from . import _lib
+
+        self._lib, self.rank, self.world = _lib, rank, world
+        lib = _lib.lib()
+
+        def make_id() -> bytes:
+            buf = ctypes.create_string_buffer(128)
+            _lib.check(lib.bark_comm_unique_id(buf))
+            return buf.raw
+
+        uid = exchange_unique_id(rank, world, addr, port, make_id)
+        self._comm = ctypes.c_void_p()
+        _lib.check(lib.bark_comm_create(ctypes.c_char_p(uid), rank, world, device, ctypes.byref(self._comm)))
+
+    def gather_mll(self, local, total: int):
+        """`gather_mll` above over this communicator: per-rank blocks (sizes from shard_range) -> (total,) on every rank."""
+        import torch
+
+        L, lib = self._lib, self._lib.lib()
+        sizes = [shard_range(total, r, self.world) for r in range(self.world)]
+        lo, hi = sizes[self.rank]
+        if local.shape[0] != hi - lo:
+            raise ValueError(f"rank {self.rank} holds {local.shape[0]} values, expected {hi - lo}")
+        widest = max(h - l for l, h in sizes)
+        send = local.contiguous()
+        if send.shape[0] != widest:
+            send = torch.zeros(widest, dtype=torch.float64, device=local.device)
+            send[: hi - lo] = local
+        out = torch.empty(widest * self.world, dtype=torch.float64, device=local.device)
+        L.check(lib.bark_allgather_mll(self._comm, L.ptr(send), widest, L.ptr(out), L.stream_ptr()))
+        if all(h - l == widest for l, h in sizes):
+            return out
+        return torch.cat([out[r * widest: r * widest + (h - l)] for r, (l, h) in enumerate(sizes)])
+
+    def all_reduce(self, t, op: str = "sum"):
+        """In place over all ranks (float64 device tensor): 'sum' (mixture moments) or 'max' (the bench's clock)."""
+        L = self._lib
+        L.check(L.lib().bark_allreduce_f64(self._comm, L.ptr(t), t.numel(), 1 if op == "max" else 0, L.stream_ptr()))
+        return t
+
+    def barrier(self):
+        import torch
+
+        one = torch.zeros(1, dtype=torch.float64, device="cuda")
+        self.all_reduce(one)
+        torch.cuda.synchronize()
+
+    def close(self):
+        if self._comm:
+            self._lib.lib().bark_comm_destroy(self._comm)
+            self._comm = None

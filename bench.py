@@ -278,14 +278,62 @@ class Workload:
         return host
 
 
-def timed_region(wl, steps, warmup, world, dist, gather):
+class TorchCollective:
+    """The exchanges of a run over torch.distributed (RCCL = the `nccl` backend, or gloo)."""
+
+    def __init__(self, dist, backend):
+        self.dist, self.backend = dist, backend
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def max_over_ranks(self, value, device):
+        import torch
+
+        t = torch.tensor([value], dtype=torch.float64, device=device if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather(self, local, total):
+        from bark_amd.distributed import gather_mll
+
+        return gather_mll(local if self.backend == "nccl" else local.cpu(), total)  # gloo moves host tensors
+
+    def close(self):
+        self.dist.destroy_process_group()
+
+
+class AbiCollective:
+    """The same exchanges through the C ABI's RCCL entry points (bark_amd.distributed.RcclGroup): no torch.distributed."""
+
+    def __init__(self, group):
+        self.group, self.backend = group, "rccl-abi"
+
+    def barrier(self):
+        self.group.barrier()
+
+    def max_over_ranks(self, value, device):
+        import torch
+
+        t = torch.tensor([value], dtype=torch.float64, device=device)
+        self.group.all_reduce(t, "max")
+        return float(t.item())
+
+    def gather(self, local, total):
+        return self.group.gather_mll(local, total)
+
+    def close(self):
+        self.group.close()
+
+
+def timed_region(wl, steps, warmup, world, coll, gather):
     """W warm-up steps, then exactly K steps between barrier + synchronize fences; max over ranks."""
     import torch
 
     def fence():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            coll.barrier()
         torch.cuda.synchronize()
 
     out = None
@@ -302,9 +350,7 @@ def timed_region(wl, steps, warmup, world, dist, gather):
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=wl.Xd.device if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = coll.max_over_ranks(elapsed, wl.Xd.device)
     call_ms = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(steps)) / steps
     return elapsed, call_ms, out
 
@@ -317,7 +363,8 @@ def require_rccl(args, world, requested) -> bool:
 
 
 def init_collective(world, rank, dev_index, requested, must_be_rccl):
-    """Process group for the one exchange of the path (the MLL gather) -> (backend in use, rccl_ranks_seen).
+    """Collective object for the one exchange of the path (the MLL gather) -> (TorchCollective | AbiCollective | None,
+    rccl_ranks_seen).  `requested`: nccl (default; torch.distributed over RCCL), gloo (dry runs), abi (RCCL through the C ABI).
     `nccl` IS RCCL on ROCm; one tiny all-reduce proves the communicator before any timed region, and its value — the
     number of ranks RCCL actually saw — goes into the JSON.  If RCCL cannot be brought up: with `must_be_rccl` the
     worker exits non-zero (the launcher then ends every rank); without it the gather falls back to gloo in the SAME
@@ -330,9 +377,21 @@ def init_collective(world, rank, dev_index, requested, must_be_rccl):
     import torch.distributed as dist
 
     kw = dict(rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+    if requested == "abi":  # RCCL through the C ABI (bark_comm_* / bark_allgather_mll): no process group at all
+        from bark_amd.distributed import RcclGroup
+
+        group = RcclGroup(rank, world, dev_index, os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                          int(os.environ.get("MASTER_PORT", "29500")) + 29)
+        probe = torch.ones(1, dtype=torch.float64, device=torch.device("cuda", dev_index))
+        group.all_reduce(probe)
+        torch.cuda.synchronize()
+        seen = int(probe.item())
+        if seen != world:
+            raise SystemExit(f"RCCL (C ABI) all-reduce probe saw {seen} ranks, expected {world}")
+        return AbiCollective(group), seen
     if requested != "nccl":
         dist.init_process_group(requested, **kw)
-        return requested, None
+        return TorchCollective(dist, requested), None
     try:
         dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), **kw)
         probe = torch.ones(1, device=torch.device("cuda", dev_index))
@@ -341,7 +400,7 @@ def init_collective(world, rank, dev_index, requested, must_be_rccl):
         seen = int(probe.item())
         if seen != world:
             raise RuntimeError(f"RCCL all-reduce probe saw {seen} ranks, expected {world}")
-        return "nccl", seen
+        return TorchCollective(dist, "nccl"), seen
     except Exception as exc:  # every rank sees the same failure
         if must_be_rccl:
             print(f"[bench rank {rank}] RCCL unavailable ({exc!r}) and --require-rccl is in force: giving up "
@@ -355,7 +414,7 @@ def init_collective(world, rank, dev_index, requested, must_be_rccl):
             pass
         os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17)
         dist.init_process_group("gloo", **kw)
-        return "gloo", None
+        return TorchCollective(dist, "gloo"), None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -371,19 +430,18 @@ def selftest_worker(args, world, rank):
     from bark_amd.distributed import gather_mll, shard_range
 
     requested = os.environ.get("BARK_BENCH_BACKEND", "gloo")
-    backend, seen = init_collective(world, rank, 0, requested, require_rccl(args, world, requested))
+    coll, seen = init_collective(world, rank, 0, requested, require_rccl(args, world, requested))
+    backend = coll.backend if coll else None
 
     def region(total, lo, hi):
         local = torch.arange(lo, hi, dtype=torch.float64)
         if world > 1:
-            dist.barrier()
+            coll.barrier()
         t0 = time.perf_counter()
-        full = gather_mll(local, total) if world > 1 else local
+        full = coll.gather(local, total) if world > 1 else local
         elapsed = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            elapsed = coll.max_over_ranks(elapsed, "cpu")
         return bool((full == torch.arange(total, dtype=torch.float64)).all()), elapsed
 
     total = args.total or args.batch * world
@@ -402,8 +460,8 @@ def selftest_worker(args, world, rank):
                           "collective_backend": backend, "rccl_ranks_seen": seen, "c4_strong": c4,
                           "launched_by": "bench.py" if os.environ.get("BARK_BENCH_WORKER") else "external"}), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        coll.barrier()
+        coll.close()
     return 0 if ok else 1
 
 
@@ -423,13 +481,14 @@ def worker(args) -> int:
     ndev = torch.cuda.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
-    backend = os.environ.get("BARK_BENCH_BACKEND", "nccl")
-    if backend == "nccl" and world > ndev:
+    backend = os.environ.get("BARK_BENCH_BACKEND", "nccl")  # nccl | gloo | abi (RCCL through the C ABI, no torch.distributed)
+    if backend in ("nccl", "abi") and world > ndev:
         raise SystemExit(f"--gpus {world} but only {ndev} devices (set BARK_BENCH_BACKEND=gloo to share a GPU in a dry run)")
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     requested = backend
-    backend, rccl_ranks_seen = init_collective(world, rank, dev_index, requested, require_rccl(args, world, requested))
+    coll, rccl_ranks_seen = init_collective(world, rank, dev_index, requested, require_rccl(args, world, requested))
+    backend = coll.backend if coll else None
 
     from bark_amd import _lib
     from bark_amd.distributed import gather_mll, shard_range
@@ -447,13 +506,11 @@ def worker(args) -> int:
     def make_gather(total_):
         if world == 1:
             return lambda t: t
-        if backend == "nccl":
-            return lambda t: gather_mll(t, total_)
-        return lambda t: gather_mll(t.cpu(), total_)  # dry run on a shared GPU: gloo moves host tensors
+        return lambda t: coll.gather(t, total_)
 
     # ---- synthetic inputs: same X, y on every rank; rank r owns forests offset .. offset+B-1
     wl = Workload(N, d, m, B, seed_base=N, rank_offset=offset, chunk=args.chunk, noise_seed=rank)
-    elapsed, call_ms, all_mll = timed_region(wl, args.steps, args.warmup, world, dist, make_gather(total))
+    elapsed, call_ms, all_mll = timed_region(wl, args.steps, args.warmup, world, coll, make_gather(total))
     mll_host = wl.check()
     assert all_mll.shape[0] == total and bool(torch.isfinite(all_mll).all())
 
@@ -462,15 +519,15 @@ def worker(args) -> int:
     if world > 1 and not strong and N == 4096:
         lo, hi = shard_range(512, rank, world)
         wl4 = Workload(N, d, m, hi - lo, seed_base=N, rank_offset=lo, noise_seed=rank)
-        e4, call4, out4 = timed_region(wl4, args.steps, args.warmup, world, dist, make_gather(512))
+        e4, call4, out4 = timed_region(wl4, args.steps, args.warmup, world, coll, make_gather(512))
         wl4.check()
         c4 = {"workload": "c4: 512 forest samples sharded over %d GPUs (%d per GPU)" % (world, hi - lo), "scaling": "strong",
               "value": 512 * args.steps / e4, "unit": "evals/s", "ms_per_step": e4 / args.steps * 1e3,
               "call_ms_rank0": call4}
         del wl4
     if world > 1:
-        dist.barrier()  # every rank leaves here; rank 0's untimed extras below run with no peer waiting in a collective
-        dist.destroy_process_group()
+        coll.barrier()  # every rank leaves here; rank 0's untimed extras below run with no peer waiting in a collective
+        coll.close()
     if rank != 0:
         return 0
 

@@ -333,6 +333,23 @@ int bark_mixture_finish_hip(const double *partial, double total, int64_t C, doub
  * leaf-vector matrices (bark_sampler.py:233-236) without host arithmetic on device data. */
 int bark_copy2d_hip(double *dst, int64_t ldd, const double *src, int64_t lds, int64_t rows, int64_t cols, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Multi-GPU exchanges over RCCL — replaces nothing in the reference, which evaluates the forest samples
+ * of `batched_forest_gram_matrix` (forest.py:92-98) one after the other in one process.  One process per GPU holds a
+ * contiguous block of samples; the ONLY data that crosses GPUs is the (B,) vector of log-likelihoods
+ * (examples/mcmc/mcmc_record_mll.py:72-74) and, for the posterior, the 2 C partial sums of the mixture moments
+ * (tree_gps.py:116-131).  librccl is loaded at run time; every function fails with BARK_ERR_HIP when it is absent.
+ *   bark_comm_unique_id   128 bytes, generated by ONE rank and handed to the others by the caller (socket, file, MPI ...)
+ *   bark_comm_create      collective over `world` ranks: communicator of this rank on `device`
+ *   bark_allgather_mll    out[r * n_local + i] = local_r[i] for every rank r (equal block sizes; device pointers; enqueued
+ *                         on `stream`)
+ *   bark_allreduce_f64    in place over all ranks: sum (op_max == 0) or maximum (op_max != 0) */
+int bark_comm_unique_id(void *id_out);
+int bark_comm_create(const void *id, int rank, int world, int device, void **comm_out);
+void bark_comm_destroy(void *comm);
+int bark_allgather_mll(void *comm, const double *local, int64_t n_local, double *out, void *stream);
+int bark_allreduce_f64(void *comm, double *buf, int64_t n, int op_max, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

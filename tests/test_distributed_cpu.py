@@ -161,3 +161,28 @@ def test_bench_parent_never_imports_torch():
     assert "torch" not in names and "bark_amd" not in names and "numpy" not in names
     launch = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "launch")
     assert not any(isinstance(n, (ast.Import, ast.ImportFrom)) for n in ast.walk(launch))
+
+
+def test_unique_id_exchange_over_tcp():
+    """The 128-byte RCCL id of the C-ABI communicator (bark_comm_unique_id) travels from rank 0 to the other ranks over a
+    plain socket (bark_amd.distributed.exchange_unique_id): three ranks as threads, late listener included."""
+    import threading
+    import time
+
+    from bark_amd.distributed import exchange_unique_id
+
+    port, world = _free_port(), 3
+    want = bytes(range(128))
+    got = {}
+
+    def rank_fn(r):
+        if r == 0:
+            time.sleep(0.3)  # the others are already retrying when rank 0 starts to listen
+        got[r] = exchange_unique_id(r, world, "127.0.0.1", port, lambda: want, timeout=30.0)
+
+    ts = [threading.Thread(target=rank_fn, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=60)
+    assert got == {0: want, 1: want, 2: want}

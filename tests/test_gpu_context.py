@@ -142,6 +142,19 @@ def test_sweep_is_hipgraph_capturable(env):
     g2.replay()
     torch.cuda.synchronize()
     assert bool((wl2.mll_d == eager2).all())
+    # matrices of one block row: leaf walk + one launch on the caller's stream
+    wl4 = bench.Workload(64, 8, 50, 32, seed_base=64, rank_offset=0)
+    wl4.run()
+    torch.cuda.synchronize()
+    eager4 = wl4.mll_d.clone()
+    g4 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g4):
+        wl4.stream = env.lib.stream_ptr()
+        wl4.run()
+    wl4.mll_d.zero_()
+    g4.replay()
+    torch.cuda.synchronize()
+    assert bool((wl4.mll_d == eager4).all()) and int(wl4.info_d.abs().max().item()) == 0
     # and the split-K look-ahead schedule (third stream: the bulk of step j+2 forks after solve(j) and joins two steps later)
     wl3 = bench.Workload(6900, 8, 50, 1, seed_base=6900, rank_offset=0)  # 54 block rows: still the split-K layout, look-ahead in the middle steps
     wl3.run()

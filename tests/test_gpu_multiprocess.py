@@ -62,3 +62,24 @@ def test_two_ranks_share_one_gpu():
     want = orc.batched_mll(F, np.linspace(0.05, 0.2, total), None, X, y, ft, include_scale=False, include_2pi=True)
     assert np.array_equal(results[0], results[1])
     assert np.allclose(results[0], want, rtol=1e-9, atol=1e-8)
+
+
+def test_rccl_through_the_c_abi_world_of_one():
+    """bark_comm_* / bark_allgather_mll / bark_allreduce_f64 (include/bark_hip.h): RCCL resolved at run time, a communicator
+    built from the C ABI alone.  One GPU per box here, so the world has one rank (two ranks cannot share a device under
+    RCCL): the gather returns the block, sum and max leave the buffer as it is, ragged totals keep their order."""
+    import torch
+
+    from bark_amd.distributed import RcclGroup
+
+    g = RcclGroup(0, 1, 0)
+    local = torch.arange(7, dtype=torch.float64, device="cuda") * 1.5
+    out = g.gather_mll(local, 7)
+    torch.cuda.synchronize()
+    assert torch.equal(out, local)
+    buf = torch.tensor([2.0, -3.0, 5.5], dtype=torch.float64, device="cuda")
+    g.all_reduce(buf)
+    g.all_reduce(buf, "max")
+    g.barrier()
+    assert buf.tolist() == [2.0, -3.0, 5.5]
+    g.close()

@@ -17,5 +17,5 @@ for f in $(cd $src && ls *.cpp *.hip); do
   objs="$objs /tmp/abv_${name}_$f.o"
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -pthread -o $ROOT/tools/ab/$name.so $objs
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -pthread -o $ROOT/tools/ab/$name.so $objs -ldl
 echo built tools/ab/$name.so
