@@ -625,8 +625,9 @@ __device__ __forceinline__ void diag_g(const double *__restrict__ Up, long ld, c
 // nkb: trailing block rows of U still to be applied to the stored diagonal tile, D = P - sum_{j-nkb <= k < j} U[k,j]'U[k,j]
 // (1 in the plain schedule, 2 in the pipelined one, 0 for j == 0).
 // want_g (pipelined schedule): also rows 0..127 of Mats::W := -U[j-1,j] W_j, the dense half of solve_kernel<1>'s left operand.
-// wait_slot >= -1 (chain-bound chunks): the launch stores its block step in p.sync[3] when it starts — the helper
-// streams' gate kernels wait for that instead of an event recorded between solve(j-1) and this kernel.  wait_slot == -2: off.
+// publish (chain-bound chunks): the launch stores its block step in p.sync[3] when it starts — the helper streams' gate
+// kernels wait for that instead of an event recorded between solve(j-1) and this kernel (diag_pre_kernel does it instead
+// when it runs in front of this one).
 // wait_slot >= 0: before it ends, the workgroup waits (bounded: ~2 s, then info = -3) until the progress counter
 // p.sync[wait_slot] has reached wait_value — the row launch whose tiles the NEXT kernel of this stream (solve(j)) reads
 // has retired.  This replaces an event wait between diag(j) and solve(j) on the caller's stream: an unresolved
@@ -636,7 +637,8 @@ __device__ __forceinline__ void diag_g(const double *__restrict__ Up, long ld, c
 // ONE: the one-launch evaluation of matrices of one block row (OneBlock; j == 0, nkb == 0) — an instantiation of its
 // own, so that the regular kernel carries none of its code (with a run-time switch diag_kernel ran 52 -> 60 us).
 template <bool ONE>
-__global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb, int want_g, int wait_slot, int wait_value, OneBlock ob) {
+__global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb, int want_g, int wait_slot, int wait_value, OneBlock ob,
+                                                          int publish) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, b = blockIdx.x;
     const Lane q = lane_of(tid);
@@ -645,7 +647,7 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
     double *tile = Ab + (size_t)j * NB * p.ld + (size_t)j * NB;
     // operands of the kernel's last phase, requested now so their latency hides behind the factorisation
     // (solve_kernel(j-1) finished updating y_j before this launch)
-    if (wait_slot >= -1 && b == 0 && tid == 0 && p.sync)  // this launch has started: everything before it on this stream is done
+    if (publish && b == 0 && tid == 0 && p.sync)  // this launch has started: everything before it on this stream is done
         __hip_atomic_store(p.sync + 3, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     constexpr bool one = ONE;
     const double y_in = tid < NB ? (one ? (tid < p.N ? ob.y[tid] : 0.0) : p.yz[(size_t)b * p.nrb * NB + (size_t)j * NB + tid]) : 0.0;
@@ -854,6 +856,41 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
         }
         if (code != 0 && (info_in == 0 || code == -3)) p.info[b] = code;
     }
+}
+
+// D = P - sum_k U[k,j]'U[k,j] over the nkb block rows above, on the 36 sub-blocks of the upper block triangle, in place in
+// the stored diagonal tile: diag_update's arithmetic (per element the same MFMA sequence: block rows in order, k ascending,
+// four k per MFMA — identical bits) by 9 workgroups x 4 waves per matrix, one sub-block per wave, operands straight from
+// L2 (solve_kernel just wrote the panel), instead of inside diag_kernel, where it is 8-16 us of a one-workgroup kernel that
+// sits on the critical path of chain-bound chunks (MFMA-bound on ONE CU: 36 x 32 MFMAs over four pipes).  diag_kernel then
+// runs with nkb = 0.  publish: store the block step in p.sync[3] (the helper streams' gates wait for it), as diag_kernel
+// does when it is the first kernel after solve(j-1).
+__global__ __launch_bounds__(THREADS) void diag_pre_kernel(Mats p, int j, int nkb, int publish) {
+    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+    if (publish && blockIdx.x == 0 && b == 0 && threadIdx.x == 0)
+        __hip_atomic_store(p.sync + 3, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int rb = 0, rem = blockIdx.x * (THREADS / 64) + wave;  // sub-block index 0 .. 35, row-major over the upper block triangle
+    while (rem >= NSB - rb) {
+        rem -= NSB - rb;
+        ++rb;
+    }
+    const int cb = rb + rem;
+    double *Ab = p.A + (size_t)b * p.bstride;
+    double *tile = Ab + (size_t)j * NB * p.ld + (size_t)j * NB;
+    double pre[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) pre[v] = tile[(size_t)(rb * 16 + lk + 4 * v) * p.ld + cb * 16 + lr];
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int a = 0; a < nkb; ++a) {
+        const double *panel = Ab + (size_t)(j - nkb + a) * NB * p.ld + (size_t)j * NB + (size_t)lk * p.ld + lr;
+#pragma unroll 8
+        for (int ks = 0; ks < NB / 4; ++ks) {
+            const double av = panel[(size_t)(ks * 4) * p.ld + rb * 16], bv = panel[(size_t)(ks * 4) * p.ld + cb * 16];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) tile[(size_t)(rb * 16 + lk + 4 * v) * p.ld + cb * 16 + lr] = pre[v] - acc[v];
 }
 
 // the row stream `slot` has finished everything up to block step `value` (one thread; runs after the row kernels
@@ -1582,6 +1619,7 @@ struct Sweep {
     // chain-bound chunks (few matrices): diag_kernel(j) itself waits, at its end, for the row launch solve(j) depends on
     // (device-side progress counter) instead of an event wait on the caller's stream; see diag_kernel
     bool dev_wait = false;
+    bool pre_update = false;  // ... and the rank-128 / 256 update of the diagonal tile runs as diag_pre_kernel
     bool dev_gate = false;  // ... and the helper streams are released by gate kernels instead of an event record
     int rep = 0;
     double *slabs = nullptr;
@@ -1632,7 +1670,7 @@ struct Sweep {
     int launch_one_block(const double *y, double *mll, const int32_t *fault, int include_2pi) {
         const OneBlock ob{y, mll, fault, include_2pi, rep};
         const size_t lds_bytes = DIAG_LDS + (size_t)p.nW * NB * sizeof(uint32_t);
-        hipLaunchKernelGGL(diag_kernel<true>, dim3((unsigned)p.Bc), dim3(THREADS), lds_bytes, main, p, 0, 0, 0, -2, 0, ob);
+        hipLaunchKernelGGL(diag_kernel<true>, dim3((unsigned)p.Bc), dim3(THREADS), lds_bytes, main, p, 0, 0, 0, -2, 0, ob, 0);
         BARK_LAUNCH_CHECK();
         return BARK_OK;
     }
@@ -1647,7 +1685,17 @@ struct Sweep {
         // pipelined schedule's row launches retire workgroups continuously: there the whole-CU request stays the
         // better choice — one N = 16384 matrix 26.6 against 28.3 ms, N = 4096 x 8 4.87 against 5.34.)
         const bool exclusive = p.Bc <= DIAG_EXCLUSIVE_MAX_BC && !lookahead(j + 1);
-        hipLaunchKernelGGL(diag_kernel<false>, dim3((unsigned)p.Bc), dim3(THREADS), exclusive ? DIAG_LDS_EXCLUSIVE : DIAG_LDS, main, p, j, nkb, want_g, wait_slot, wait_value, OneBlock{});
+        int publish = wait_slot >= -1 ? 1 : 0;
+        // chain-bound chunks: the update of the diagonal tile by its block rows above as a launch of its own in front of
+        // the one-workgroup kernel (diag_pre_kernel)
+        if (pre_update && nkb > 0) {
+            hipLaunchKernelGGL(diag_pre_kernel, dim3(NBLK / (THREADS / 64), (unsigned)p.Bc), dim3(THREADS), 0, main, p, j, nkb, publish);
+            BARK_LAUNCH_CHECK();
+            nkb = 0;
+            publish = 0;
+        }
+        hipLaunchKernelGGL(diag_kernel<false>, dim3((unsigned)p.Bc), dim3(THREADS), exclusive ? DIAG_LDS_EXCLUSIVE : DIAG_LDS, main, p, j, nkb,
+                           want_g, wait_slot, wait_value, OneBlock{}, publish);
         BARK_LAUNCH_CHECK();
         return mark_on(main);
     }
@@ -2179,6 +2227,10 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
         // gates | end-of-diag wait only | events, ms): pipelined N = 4096 x 8 4.44 | 4.59 | 4.64, N = 8192 x 2 8.18 | 8.35 |
         // 8.48; split-K layout N = 4096 x 1 2.19 | 2.14 | 2.22, N = 1024 x 1 0.575 | 0.520 | 0.534 — pipelined only
         sw.dev_gate = sw.dev_wait && sw.pipelined;
+        // split-K layout only: same box, this | inside diag_kernel, ms — N = 4096 x 1 2.035 | 2.130, N = 1024 x 1 0.492 | 0.514,
+        // N = 2048 x 4 1.082 | 1.125; in the pipelined schedule the extra launch queues for slots behind the resident row
+        // workgroups like every kernel of the chain does (N = 4096 x 8 4.77 | 4.46, x 16 7.61 | 7.11, N = 16384 x 1 27.2 | 25.4)
+        sw.pre_update = splitk && bc <= DEVWAIT_MAX_BC;
         if ((rc = prologue(c0, bc))) return rc;
         for (int j = 0; j < nrb; ++j)
             if ((rc = sw.step(j))) return rc;
