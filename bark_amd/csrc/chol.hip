@@ -2226,7 +2226,13 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
         // gate kernels in place of the event record that releases the row streams: measured (one process per variant,
         // gates | end-of-diag wait only | events, ms): pipelined N = 4096 x 8 4.44 | 4.59 | 4.64, N = 8192 x 2 8.18 | 8.35 |
         // 8.48; split-K layout N = 4096 x 1 2.19 | 2.14 | 2.22, N = 1024 x 1 0.575 | 0.520 | 0.534 — pipelined only
+        // ... split-K layout: only for sweeps with look-ahead steps (N = 6900 x 1 5.02 -> 4.59 with gates; without look-ahead
+        // they cost: N = 4096 x 1 2.04 -> 2.28, N = 2048 x 4 1.09 -> 1.21)
         sw.dev_gate = sw.dev_wait && sw.pipelined;
+        if (sw.dev_wait && !sw.pipelined) {
+            sw.p.Bc = (int)bc;  // lookahead() reads the chunk size
+            for (int jj = 2; jj < nrb && !sw.dev_gate; ++jj) sw.dev_gate = sw.lookahead(jj);
+        }
         // split-K layout only: same box, this | inside diag_kernel, ms — N = 4096 x 1 2.035 | 2.130, N = 1024 x 1 0.492 | 0.514,
         // N = 2048 x 4 1.082 | 1.125; in the pipelined schedule the extra launch queues for slots behind the resident row
         // workgroups like every kernel of the chain does (N = 4096 x 8 4.77 | 4.46, x 16 7.61 | 7.11, N = 16384 x 1 27.2 | 25.4)
