@@ -1487,6 +1487,10 @@ constexpr int64_t SPLITK_LAYOUT_MAX_WORK = BARK_SPLITK_LAYOUT_MAX_WORK;
 #define BARK_PIPE_MIN_NRB 8
 #endif
 constexpr int PIPE_MIN_NRB = BARK_PIPE_MIN_NRB;  // fewer block rows: plain schedule (no difference measured at N = 512..896)
+#ifndef BARK_PLAIN_CHUNK_MULTIPLE
+#define BARK_PLAIN_CHUNK_MULTIPLE 256
+#endif
+constexpr int PLAIN_CHUNK_MULTIPLE = BARK_PLAIN_CHUNK_MULTIPLE;  // chunks of a multiple of this many matrices (and > 16 block rows): plain
 #ifndef BARK_SOLVE_NARROW_MAX_WGS
 #define BARK_SOLVE_NARROW_MAX_WGS 256
 #endif
@@ -2205,7 +2209,7 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
     if ((rc = sw.mark_on(caller))) return rc;
     for (int64_t c0 = 0; c0 < B; c0 += Bc) {  // chunks of Bc resident matrices, one after the other
         const int64_t bc = (B - c0 < Bc) ? (B - c0) : Bc;
-        sw.pipelined = pipeline_ok && ((bc % 256) != 0 || nrb <= 16);
+        sw.pipelined = pipeline_ok && ((bc % PLAIN_CHUNK_MULTIPLE) != 0 || nrb <= 16);
         if (nrb == 1 && fused && C == 0 && !timing) {  // N <= 128: leaf walk + ONE launch per chunk (OneBlock)
             Mats &p1 = sw.p;
             bark_pack_info sub = *info;
@@ -2377,7 +2381,7 @@ static int leafspace_run(bark_ctx *ctx, const void *packed, const bark_pack_info
         const char *packed_c = static_cast<const char *>(packed) + (size_t)c0 * m * info->stride * 16;
         p.info = info_out + c0;
         p.Bc = (int)bc;
-        sw.pipelined = !g.L.splitk && nrb >= PIPE_MIN_NRB && ((bc % 256) != 0 || nrb <= 16);  // as the dense entry
+        sw.pipelined = !g.L.splitk && nrb >= PIPE_MIN_NRB && ((bc % PLAIN_CHUNK_MULTIPLE) != 0 || nrb <= 16);  // as the dense entry
         if ((rc = walk_one_hot(packed_c, &sub, X, N, d, (int)g.W, codes, ctx->fault, caller))) return rc;
         rc = leafspace_prepare(codes, (int)g.W, (int)g.npad, planes, (int)g.R, (int)g.Rpad, noise + c0,
                                use_scale ? scale + c0 : nullptr, (int)m, (int)bc, p.A, p.ld, p.bstride, y, (int)N, p.yz,
