@@ -1254,6 +1254,73 @@ __global__ __launch_bounds__(THREADS, 2) void solve_narrow_kernel(Mats p, int j,
     if (tid < WCOLS) y_commit(part, p.yz + (size_t)b * p.nrb * NB + (size_t)cb * NB, c0 + tid);
 }
 
+// ---------------------------------------------------------------------------------------------
+// solve_direct_kernel: the same U[j,i] = W_j' T[j,i] for the critical path of lone matrices, where the launch is bound by
+// LATENCY, not work: solve_narrow_kernel stages eight (DEF: sixteen) k-tiles through LDS one DMA round trip after the other
+// (10.4 us per launch whether it solves one tile or thirty-one — a sixth of a lone matrix's block step).  Here a tile's 128
+// columns go to 8 workgroups of 16, wave w owns the row tiles w and 7 - w (9 of the 36 non-zero (k-tile, row-tile) products
+// each), and both MFMA operands come straight from L2 — diag_kernel and the reduce kernel have just written them — with
+// every load of the wave independent of the others (straight-line code per wave: template on the wave index).  Per element the
+// MFMA sequence (k ascending, four k per MFMA, zero k-tiles of W_j skipped) and the right-hand-side update are those of
+// solve_kernel: identical results.
+// ---------------------------------------------------------------------------------------------
+template <int DEF, int WV>
+__device__ __forceinline__ void solve_direct_wave(const double *__restrict__ Wl, const double *__restrict__ Tl, long ld, f64x4 &accA,
+                                                  f64x4 &accB) {
+    constexpr int rtA = WV, rtB = 7 - WV;  // rtA < rtB
+    if (DEF) {  // dense block [-G_j]' U[j-1,i] first
+#pragma unroll
+        for (int ks = 0; ks < NB / 4; ++ks) {
+            const double bv = Tl[(size_t)(ks * 4) * ld];
+            accA = __builtin_amdgcn_mfma_f64_16x16x4f64(Wl[(ks * 4) * NB + rtA * 16], bv, accA, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f64_16x16x4f64(Wl[(ks * 4) * NB + rtB * 16], bv, accB, 0, 0, 0);
+        }
+        Wl += (size_t)NB * NB;
+        Tl += (size_t)NB * ld;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4 * (rtB + 1); ++ks) {
+        const double bv = Tl[(size_t)(ks * 4) * ld];
+        if (ks < 4 * (rtA + 1)) accA = __builtin_amdgcn_mfma_f64_16x16x4f64(Wl[(ks * 4) * NB + rtA * 16], bv, accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f64_16x16x4f64(Wl[(ks * 4) * NB + rtB * 16], bv, accB, 0, 0, 0);
+    }
+}
+
+template <int DEF>
+__global__ __launch_bounds__(THREADS) void solve_direct_kernel(Mats p, int j, int n_right) {
+    __shared__ double part[NSB_ROWS * NB];
+    const int tid = threadIdx.x;
+    int b, ts;
+    if (!xcd_map(blockIdx.x, n_right * 8, p.Bc, b, ts)) return;
+    const Lane q = lane_of(tid);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = ts >> 3, c0 = (ts & 7) * 16, cb = j + 1 + t;
+    double *tile = p.A + (size_t)b * p.bstride + (size_t)j * NB * p.ld + (size_t)cb * NB;
+    const double *Wl = p.W + (size_t)b * W_STRIDE + (size_t)(1 - DEF) * NB * NB + (size_t)q.lk * NB + q.lr;  // [-G_j ;] W_j
+    const double *Tl = tile - (size_t)DEF * NB * p.ld + (size_t)q.lk * p.ld + c0 + q.lr;                       // [U[j-1,i] ;] T[j,i]
+    f64x4 acc[2][1] = {{{0.0, 0.0, 0.0, 0.0}}, {{0.0, 0.0, 0.0, 0.0}}};
+    if (wave == 0)
+        solve_direct_wave<DEF, 0>(Wl, Tl, p.ld, acc[0][0], acc[1][0]);
+    else if (wave == 1)
+        solve_direct_wave<DEF, 1>(Wl, Tl, p.ld, acc[0][0], acc[1][0]);
+    else if (wave == 2)
+        solve_direct_wave<DEF, 2>(Wl, Tl, p.ld, acc[0][0], acc[1][0]);
+    else
+        solve_direct_wave<DEF, 3>(Wl, Tl, p.ld, acc[0][0], acc[1][0]);
+    const int rt[2] = {wave, 7 - wave};
+    __syncthreads();  // in place: every wave has read its T rows of the strip before any row of it is overwritten
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) tile[(size_t)(rt[h] * 16 + q.lk + 4 * v) * p.ld + c0 + q.lr] = acc[h][0][v];
+    if (cb >= p.nrb) return;  // candidate columns: no right-hand-side update
+    const double *zb = p.yz + (size_t)b * p.nrb * NB + (size_t)j * NB;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) y_partial<1>(acc[h], rt[h], zb, part, c0, q);
+    __syncthreads();
+    if (tid < 16) y_commit(part, p.yz + (size_t)b * p.nrb * NB + (size_t)cb * NB, c0 + tid);
+}
+
 // right-hand-side block := identity (N x N inside the padded candidate columns)
 __global__ void identity_rhs_kernel(Mats p, int N, int cpad) {
     const int b = blockIdx.z, r = blockIdx.y;
@@ -1499,6 +1566,10 @@ constexpr int PLAIN_CHUNK_MULTIPLE = BARK_PLAIN_CHUNK_MULTIPLE;  // chunks of a 
 #endif
 // a solve of at most this many workgroups after sharing its tiles' columns out goes narrow (look-ahead / pipelined schedule)
 constexpr long SOLVE_NARROW_MAX_WGS = BARK_SOLVE_NARROW_MAX_WGS, PIPE_NARROW_MAX_WGS = BARK_PIPE_NARROW_MAX_WGS;
+#ifndef BARK_SOLVE_DIRECT_MAX_WGS
+#define BARK_SOLVE_DIRECT_MAX_WGS 512
+#endif
+constexpr long SOLVE_DIRECT_MAX_WGS = BARK_SOLVE_DIRECT_MAX_WGS;  // ... at most this many after sharing out over 8: solve_direct_kernel
 
 #ifndef BARK_DEVWAIT_MAX_BC
 #define BARK_DEVWAIT_MAX_BC 32
@@ -1886,7 +1957,9 @@ struct Sweep {
             if (timed) solve_marks.push_back(ev.size());
             if ((r = mark_on(s))) return r;
             // few tiles (the critical path of lone matrices): share a tile's columns out over 4 or 2 workgroups
-            if ((long)n_right * bc * 4 <= SOLVE_NARROW_MAX_WGS)
+            if ((long)n_right * bc * 8 <= SOLVE_DIRECT_MAX_WGS)
+                hipLaunchKernelGGL(solve_direct_kernel<0>, dim3(xcd_grid(n_right * 8, bc)), dim3(THREADS), 0, s, p, j, n_right);
+            else if ((long)n_right * bc * 4 <= SOLVE_NARROW_MAX_WGS)
                 hipLaunchKernelGGL(solve_narrow_kernel<1>, dim3(xcd_grid(n_right * 4, bc)), dim3(THREADS), GEMM_LDS, s, p, j, n_right);
             else if ((long)n_right * bc * 2 <= SOLVE_NARROW_MAX_WGS)
                 hipLaunchKernelGGL(solve_narrow_kernel<2>, dim3(xcd_grid(n_right * 2, bc)), dim3(THREADS), GEMM_LDS, s, p, j, n_right);
