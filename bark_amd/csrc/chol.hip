@@ -582,6 +582,31 @@ __device__ __forceinline__ void diag_update(const double *__restrict__ tile, lon
     }
 }
 
+// nkb == 0 (diag_pre_kernel has applied the block rows above, or j == 0): the stored tile only moves into the packed image.
+// Wave 0 stores the sub-block (0,0) first and eliminates it while its other loads — and the other waves' — are still in
+// flight (the tile load and factor16(0) used to be 4 K + 6 K cycles one after the other, with three waves idle in the second).
+template <int W>
+__device__ __forceinline__ void diag_copy(const double *__restrict__ tile, long ld, double *S, int lane, int lr, int lk, double &logsum,
+                                          int &bad) {
+    using T = UpperBlocks<W>;
+    double pre[9][4];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) pre[i][v] = tile[(size_t)(T::rb[i] * 16 + lk + 4 * v) * ld + T::cb[i] * 16 + lr];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        double *blk = S + blk_off(T::rb[i], T::cb[i]);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) blk[(lk + 4 * v) * SB + lr] = pre[i][v];
+        if (W == 0 && i == 0) {  // UpperBlocks<0>: sub-block (0,0)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            factor16(blk, lane, 0, logsum, bad);
+        }
+    }
+}
+
 // G_j = U[j-1,j] W_j for diag_kernel's epilogue (pipelined schedule; W_j upper triangular: column block cbk sums the
 // row blocks rbk <= cbk).  Wave w owns the 16-row blocks 2w, 2w+1 of G.  A fragments (U[j-1,j], 16 rows x 4 columns per
 // MFMA) come straight from L2 — solve(j-1) wrote the tile just before — and the B fragments are the sub-blocks of W_j
@@ -666,7 +691,20 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
         for (int e = tid; e < p.nW * NB; e += THREADS) codes[e] = lb[e];
         __syncthreads();
     }
-    {
+    double logsum = 0.0;
+    int bad = 0;
+    const bool copy_only = !ONE && nkb == 0;  // workgroup-uniform
+    if (copy_only) {
+        const int wsel = __builtin_amdgcn_readfirstlane(wave);
+        if (wsel == 0)
+            diag_copy<0>(tile, p.ld, S, lane, q.lr, q.lk, logsum, bad);
+        else if (wsel == 1)
+            diag_copy<1>(tile, p.ld, S, lane, q.lr, q.lk, logsum, bad);
+        else if (wsel == 2)
+            diag_copy<2>(tile, p.ld, S, lane, q.lr, q.lk, logsum, bad);
+        else
+            diag_copy<3>(tile, p.ld, S, lane, q.lr, q.lk, logsum, bad);
+    } else {
         // D = P - sum_k U[k,j]'U[k,j] on the upper block triangle (the product stages alias S: the update's last barrier
         // precedes the writes of S)
         const double *prev = Ab + (size_t)(j - nkb) * NB * p.ld + (size_t)j * NB;  // U[j-nkb, j]
@@ -694,16 +732,18 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
     // A wave owns whole ROWS of X (rows {0,6}, {1,4}, {2,3,5}: balanced), so the X[rb,k] it reads are its own stores,
     // and a column of X is written one step after it was computed, when nobody reads the U blocks it replaces any more.
     // Same MFMA chain per element as the unpipelined order: identical results.
-    double logsum = 0.0;
-    int bad = 0;
     const int lr = q.lr, lk = q.lk;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    // rows of X owned by this wave (-1: none); wave 0 owns none
-    const int xrow[3] = {wave_u == 1 ? 0 : wave_u == 2 ? 1 : wave_u == 3 ? 2 : -1,
-                         wave_u == 1 ? 6 : wave_u == 2 ? 4 : wave_u == 3 ? 3 : -1, wave_u == 3 ? 5 : -1};
+    // rows of X owned by this wave (-1: none).  Full tiles: {0,5}, {1,4}, {2,3} for waves 1-3 (7 + 2, 6 + 3, 5 + 4 block products
+    // in the last step, the longest) and row 6 — one product, in the last step, when wave 0 has no elimination left — for
+    // wave 0.  One-block-row matrices (any number of live sub-blocks): {0,6}, {1,4}, {2,3,5}, none for wave 0.
+    const int xrow[3] = {wave_u == 1 ? 0 : wave_u == 2 ? 1 : wave_u == 3 ? 2 : (ONE ? -1 : 6),
+                         wave_u == 1 ? (ONE ? 6 : 5) : wave_u == 2 ? 4 : wave_u == 3 ? 3 : -1, (ONE && wave_u == 3) ? 5 : -1};
     f64x4 pend[3];  // column kb of X for the owned rows, stored at the start of the next step
-    if (wave_u == 0) factor16(S + blk_off(0, 0), lane, 0, logsum, bad);
-    __syncthreads();
+    if (!copy_only) {
+        if (wave_u == 0) factor16(S + blk_off(0, 0), lane, 0, logsum, bad);
+        __syncthreads();
+    }
     // one-block-row matrices of fewer than 113 points: the sub-blocks beyond the last live one are identity padding — their
     // factor, their inverse and their share of log|D| are what the tile generation left there, nothing to compute
     const int nsb = one ? (p.N + SB - 1) / SB : NSB;
@@ -717,8 +757,8 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
             for (int v = 0; v < 4; ++v) blk[(lk + 4 * v) * SB + lr] = u[v];
         }
         __syncthreads();
-        if (wave_u == 0) {
-            if (kb + 1 < nsb) {
+        if (wave_u == 0 && kb + 1 < nsb) {
+            {
                 const double *urow = S + blk_off(kb, kb + 1);
                 double *dst = S + blk_off(kb + 1, kb + 1);
                 f64x4 u = {0.0, 0.0, 0.0, 0.0};
@@ -772,7 +812,7 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
         }
         __syncthreads();
     }
-    if (wave_u != 0) {  // last column of X
+    {  // last column of X
 #pragma unroll
         for (int i = 0; i < 3; ++i)
             if (xrow[i] >= 0 && xrow[i] < nsb - 1) {
@@ -787,12 +827,18 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
     // tile; the diagonal sub-blocks are upper triangular with exact zeros already) --------------------------------
     double *Wb = w_block(p, b);
     if (!one) {  // (nobody reads W_0 of a one-block-row matrix)
-        const int r = tid >> 4, c = tid & 15;  // one element of every 16 x 16 sub-block per thread
+        // the 36 sub-blocks on or above the block diagonal only: every consumer skips the k-tiles below it (gemm_upper_tri,
+        // solve_narrow_kernel, solve_direct_kernel), so what the buffer holds there never reaches an MFMA.  Two doubles per
+        // thread, the two halves of the workgroup on alternate sub-blocks.
+        const int half = __builtin_amdgcn_readfirstlane(tid >> 7), e = 2 * (tid & 127), r = e >> 4, c = e & 15;
+        int cnt = 0;
 #pragma unroll
         for (int rbk = 0; rbk < NSB; ++rbk)
 #pragma unroll
-            for (int cbk = 0; cbk < NSB; ++cbk)
-                Wb[(size_t)(rbk * SB + r) * NB + cbk * SB + c] = rbk <= cbk ? S[blk_off(rbk, cbk) + tid] : 0.0;
+            for (int cbk = rbk; cbk < NSB; ++cbk, ++cnt)
+                if ((cnt & 1) == half)
+                    *reinterpret_cast<f64x2 *>(Wb + (size_t)(rbk * SB + r) * NB + cbk * SB + c) =
+                        *reinterpret_cast<const f64x2 *>(S + blk_off(rbk, cbk) + e);
     }
 
     if (want_g)  // workgroup-uniform
