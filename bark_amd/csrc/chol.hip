@@ -358,6 +358,24 @@ __device__ __forceinline__ double row_bcast_f64(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// v of lane (g', c) for g' = 0..3, in every lane of column c (lane = 16 g + c): gfx950's row swaps — v_permlane32_swap leaves
+// rows {0,1,0,1} | {2,3,2,3} of the wave, v_permlane16_swap then row 0 | 1 (2 | 3) in all four — six VALU instructions per
+// double instead of eight ds_bpermute through the LDS crossbar, which the other three waves' MFMA operand reads keep busy
+// (factor16 ran 6.3 K cycles in the first sub-block steps and 8.2 K in the last ones).
+__device__ __forceinline__ void gather_rows(double v, double &r0, double &r1, double &r2, double &r3) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto l32 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto h32 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const auto l01 = __builtin_amdgcn_permlane16_swap(l32[0], l32[0], false, false);
+    const auto h01 = __builtin_amdgcn_permlane16_swap(h32[0], h32[0], false, false);
+    const auto l23 = __builtin_amdgcn_permlane16_swap(l32[1], l32[1], false, false);
+    const auto h23 = __builtin_amdgcn_permlane16_swap(h32[1], h32[1], false, false);
+    r0 = __hiloint2double((int)h01[0], (int)l01[0]);
+    r1 = __hiloint2double((int)h01[1], (int)l01[1]);
+    r2 = __hiloint2double((int)h23[0], (int)l23[0]);
+    r3 = __hiloint2double((int)h23[1], (int)l23[1]);
+}
+
 // Four elimination steps of factor16 at once (pivots K0 = 4Q .. K0+3) on [D | I]; lane (g, c) holds rows g + 4v of
 // column c in e[v] / f[v].  The four pivot rows of block Q are register Q of the four lane groups, so
 //   * their entries at this lane's column cross lane groups once per BLOCK (8 ds_bpermute, issued first) instead of
@@ -371,10 +389,9 @@ template <int Q>
 __device__ __forceinline__ void block4(double (&e)[4], double (&f)[4], double (&piv)[4][4], int c, int g, int base_index,
                                        int &bad) {
     constexpr int K0 = 4 * Q;
-    double A0 = __shfl(e[Q], 0 * 16 + c), A1 = __shfl(e[Q], 1 * 16 + c), A2 = __shfl(e[Q], 2 * 16 + c),
-           A3 = __shfl(e[Q], 3 * 16 + c);  // D[K0 + j][c]
-    double S0 = __shfl(f[Q], 0 * 16 + c), S1 = __shfl(f[Q], 1 * 16 + c), S2 = __shfl(f[Q], 2 * 16 + c),
-           S3 = __shfl(f[Q], 3 * 16 + c);  // I[K0 + j][c]
+    double A0, A1, A2, A3, S0, S1, S2, S3;
+    gather_rows(e[Q], A0, A1, A2, A3);  // D[K0 + j][c]
+    gather_rows(f[Q], S0, S1, S2, S3);  // I[K0 + j][c]
     const double P00 = readlane_f64(e[Q], 0 * 16 + K0 + 0), P01 = readlane_f64(e[Q], 0 * 16 + K0 + 1),
                  P02 = readlane_f64(e[Q], 0 * 16 + K0 + 2), P03 = readlane_f64(e[Q], 0 * 16 + K0 + 3),
                  P11 = readlane_f64(e[Q], 1 * 16 + K0 + 1), P12 = readlane_f64(e[Q], 1 * 16 + K0 + 2),
