@@ -664,6 +664,54 @@ __device__ __forceinline__ void diag_g(const double *__restrict__ Up, long ld, c
     }
 }
 
+// Column kb of the block inverse for the row rb of X a wave owns (rb < kb):  X[rb,kb] = -(sum_{rb<=k<kb} X[rb,k] U[k,kb]) W_kk,
+// computed TRANSPOSED and kept in registers.  xt[d] is the MFMA accumulator (D layout) of X[rb,rb+d]' — which is exactly the B
+// fragment of the product  t' = sum_k U[k,kb]' X[rb,k]'  (A fragments: the k-major U blocks, read from LDS without bank
+// conflicts), and t' in its D layout is the B fragment of  X[rb,kb]' = -(W_kk' t').  So a row's blocks never come back from
+// LDS (read row-major as A operands they are 8/16-way bank-conflicted: ~1 K cycles per block product, 9 K for the last column),
+// and the per-wave transpose scratch with its two wave barriers per entry is gone.  Per element the same products are summed
+// in the same order as X U and t W_kk (k ascending, four k per MFMA): identical bits.  Returns X[rb,kb]' (stored to the packed
+// image one step later, transposed back).
+// A 16 x 16 block held as an MFMA A fragment (lane (lr, lk), register v: M[lr][lk + 4v]) -> the same block in the D layout
+// (M[lk + 4v][lr]), by four MFMAs with the identity as B — exact (x * 1 + zeros; only the sign of a zero can change).  The
+// lane pattern the other way round is a 16-double-stride LDS access: 8/16-way bank conflicts that stall the LDS pipeline of
+// the whole CU, i.e. the elimination chain of wave 0 too.
+__device__ __forceinline__ f64x4 frag_transpose(const f64x4 &a, int lr, int lk) {
+    f64x4 d = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < SB / 4; ++kk) d = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], (lk + 4 * kk == lr) ? 1.0 : 0.0, d, 0, 0, 0);
+    return d;
+}
+
+template <int L>
+__device__ __forceinline__ f64x4 x_entry(f64x4 (&xt)[L], int rb, int kb, const double *S, const double *dblk, int lr, int lk) {
+    if (kb == rb + 1) {  // X[rb,rb] = W_rb (factor16 left it in S, row-major): read k-major, turned in registers
+        const double *w = S + blk_off(rb, rb);
+        f64x4 wk;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) wk[v] = w[(lk + 4 * v) * SB + lr];
+        xt[0] = frag_transpose(wk, lr, lk);
+    }
+    f64x4 t = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int d = 0; d < L; ++d) {
+        const int k = rb + d;
+        if (k < kb) {  // wave-uniform (MFMA ignores EXEC)
+            const double *ub = S + blk_off(k, kb);
+#pragma unroll
+            for (int kk = 0; kk < SB / 4; ++kk) t = __builtin_amdgcn_mfma_f64_16x16x4f64(ub[(kk * 4 + lk) * SB + lr], xt[d][kk], t, 0, 0, 0);
+        }
+    }
+    f64x4 x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < SB / 4; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(dblk[(kk * 4 + lk) * SB + lr], t[kk], x, 0, 0, 0);
+    x = -x;
+#pragma unroll
+    for (int d = 1; d < L; ++d)
+        if (rb + d == kb) xt[d] = x;
+    return x;
+}
+
 // nkb: trailing block rows of U still to be applied to the stored diagonal tile, D = P - sum_{j-nkb <= k < j} U[k,j]'U[k,j]
 // (1 in the plain schedule, 2 in the pipelined one, 0 for j == 0).
 // want_g (pipelined schedule): also rows 0..127 of Mats::W := -U[j-1,j] W_j, the dense half of solve_kernel<1>'s left operand.
@@ -698,7 +746,6 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
     const int info_in = (tid == 0 && !one) ? p.info[b] : 0;
 
     double *S = lds;                                          // packed upper block triangle, NBLK x [16][16]
-    double *scratch = lds + NBLK * SB * SB + wave * SB * TS;  // per-wave [16][TS]
     double *vec = lds + NBLK * SB * SB + 4 * SB * TS;         // [2][128] y | upper-half partial sums
     double *red = vec + 2 * NB;                               // [8]
     uint32_t *codes = nullptr;
@@ -738,7 +785,7 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
     __syncthreads();
 
     // --- blocked Cholesky D = U'U and X = U^-1, software-pipelined over the four waves ------------------------------
-    // The serial part is the eight 16x16 eliminations (factor16, one wave, ~5.8 K cycles each).  Wave 0 runs that
+    // The serial part is the eight 16x16 eliminations (factor16, one wave, ~5.4 K cycles each).  Wave 0 runs that
     // chain: in step kb it updates only the NEXT diagonal sub-block with row kb and factors it, while waves 1-3 do the
     // rest of step kb's trailing update (C) and the column kb of the inverse — so neither waits for the other:
     //   top of step kb (all waves)  (B) U[kb,cb] = W_kk' D[kb,cb], cb > kb                       | barrier
@@ -746,8 +793,8 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
     //   waves 1-3                   store column kb-1 of X (computed last step, held in registers);
     //                               (C) D[rb,cb] -= U[kb,rb]'U[kb,cb] for the other (rb, cb);
     //                               X[rb,kb] = -(sum_{rb<=k<kb} X[rb,k] U[k,kb]) W_kk  -> registers           | barrier
-    // A wave owns whole ROWS of X (rows {0,6}, {1,4}, {2,3,5}: balanced), so the X[rb,k] it reads are its own stores,
-    // and a column of X is written one step after it was computed, when nobody reads the U blocks it replaces any more.
+    // A wave owns whole ROWS of X and keeps their blocks in registers (x_entry); a column of X goes to the packed image one
+    // step after it was computed, when nobody reads the U blocks it replaces any more.
     // Same MFMA chain per element as the unpipelined order: identical results.
     const int lr = q.lr, lk = q.lk;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -756,7 +803,7 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
     // wave 0.  One-block-row matrices (any number of live sub-blocks): {0,6}, {1,4}, {2,3,5}, none for wave 0.
     const int xrow[3] = {wave_u == 1 ? 0 : wave_u == 2 ? 1 : wave_u == 3 ? 2 : (ONE ? -1 : 6),
                          wave_u == 1 ? (ONE ? 6 : 5) : wave_u == 2 ? 4 : wave_u == 3 ? 3 : -1, (ONE && wave_u == 3) ? 5 : -1};
-    f64x4 pend[3];  // column kb of X for the owned rows, stored at the start of the next step
+    f64x4 pend[3];  // column kb of X (transposed, see x_entry) for the owned rows, stored at the start of the next step
     if (!copy_only) {
         if (wave_u == 0) factor16(S + blk_off(0, 0), lane, 0, logsum, bad);
         __syncthreads();
@@ -764,18 +811,24 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
     // one-block-row matrices of fewer than 113 points: the sub-blocks beyond the last live one are identity padding — their
     // factor, their inverse and their share of log|D| are what the tile generation left there, nothing to compute
     const int nsb = one ? (p.N + SB - 1) / SB : NSB;
-    for (int kb = 0; kb < nsb; ++kb) {
-        double *dblk = S + blk_off(kb, kb);  // W_kk
-        for (int cb = kb + 1 + wave_u; cb < nsb; cb += 4) {  // (B)
+    auto phase_b = [&](int kb, double *dblk) {  // (B) U[kb,cb] = W_kk' D[kb,cb]
+        for (int cb = kb + 1 + wave_u; cb < nsb; cb += 4) {
             double *blk = S + blk_off(kb, cb);
             f64x4 u = {0.0, 0.0, 0.0, 0.0};
             mfma_tn(u, dblk, SB, blk, SB, lr, lk);
 #pragma unroll
             for (int v = 0; v < 4; ++v) blk[(lk + 4 * v) * SB + lr] = u[v];
         }
-        __syncthreads();
-        if (wave_u == 0 && kb + 1 < nsb) {
-            {
+    };
+    // Wave 0 and waves 1-3 run the loop as two separate code regions (same barriers, two per step, in both): the elimination's
+    // registers and the X rows the other waves keep in registers then never coexist in one wave's allocation.
+    if (wave_u == 0) {
+        f64x4 xw[2];  // row nsb - 2 of X from the diagonal on (full tiles only)
+        for (int kb = 0; kb < nsb; ++kb) {
+            double *dblk = S + blk_off(kb, kb);  // W_kk
+            phase_b(kb, dblk);
+            __syncthreads();
+            if (kb + 1 < nsb) {
                 const double *urow = S + blk_off(kb, kb + 1);
                 double *dst = S + blk_off(kb + 1, kb + 1);
                 f64x4 u = {0.0, 0.0, 0.0, 0.0};
@@ -785,57 +838,79 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 factor16(dst, lane, (kb + 1) * SB, logsum, bad);
+            } else if (!ONE) {  // last step: nothing left to eliminate — the one entry of X's row 6
+                pend[0] = x_entry(xw, xrow[0], kb, S, dblk, lr, lk);
             }
-        } else {
-            if (kb >= 2) {  // column kb-1 of X, computed in the previous step
+            __syncthreads();
+        }
+    } else {
+        f64x4 xt0[7], xt1[4], xt2[ONE ? 2 : 1];  // the owned rows' blocks from the diagonal on (rows {0,1,2} | {3,4,5,6} | {5})
+        for (int kb = 0; kb < nsb; ++kb) {
+            double *dblk = S + blk_off(kb, kb);  // W_kk
+            phase_b(kb, dblk);
+            __syncthreads();
+            if (kb >= 2) {  // column kb-1 of X, computed in the previous step (held transposed: lane (lr, lk) has X[lr][lk + 4v])
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
                     if (xrow[i] >= 0 && xrow[i] < kb - 1) {
                         double *dst = S + blk_off(xrow[i], kb - 1);
+                        const f64x4 xs = frag_transpose(pend[i], lr, lk);
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) dst[(lk + 4 * v) * SB + lr] = pend[i][v];
+                        for (int v = 0; v < 4; ++v) dst[(lk + 4 * v) * SB + lr] = xs[v];
                     }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
             }
-            int pair = 0;
-            for (int rb = kb + 1; rb < nsb; ++rb)  // (C), all but the next diagonal sub-block
-                for (int cb = rb; cb < nsb; ++cb) {
-                    if (rb == kb + 1 && cb == kb + 1) continue;
-                    if (pair++ % 3 + 1 != wave_u) continue;
-                    f64x4 u = {0.0, 0.0, 0.0, 0.0};
-                    mfma_tn(u, S + blk_off(kb, rb), SB, S + blk_off(kb, cb), SB, lr, lk);
-                    double *dst = S + blk_off(rb, cb);
+            {  // (C), all but the next diagonal sub-block: block p of the row-major list goes to wave p % 3 + 1, which takes its
+               // blocks two at a time — two independent MFMA chains interleaved (one at a time: ~960 cycles per block, and the
+               // first sub-block steps waited for these waves)
+                const int n = nsb - 1 - kb, total = n * (n + 1) / 2 - 1;
+                auto decode = [&](int idx, int &rb, int &cb) {
+                    int r = 0, rem = idx + 1;  // + 1: the list starts after (kb+1, kb+1)
+                    while (rem >= n - r) {
+                        rem -= n - r;
+                        ++r;
+                    }
+                    rb = kb + 1 + r;
+                    cb = rb + rem;
+                };
+                for (int i0 = wave_u - 1; i0 < total; i0 += 6) {
+                    int rb0, cb0, rb1, cb1;
+                    decode(i0, rb0, cb0);
+                    const bool two = i0 + 3 < total;
+                    decode(two ? i0 + 3 : i0, rb1, cb1);
+                    const double *a0 = S + blk_off(kb, rb0), *b0 = S + blk_off(kb, cb0);
+                    const double *a1 = S + blk_off(kb, rb1), *b1 = S + blk_off(kb, cb1);
+                    f64x4 u0 = {0.0, 0.0, 0.0, 0.0}, u1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) dst[(lk + 4 * v) * SB + lr] -= u[v];
+                    for (int kk = 0; kk < SB / 4; ++kk) {
+                        const int o = (kk * 4 + lk) * SB + lr;
+                        u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[o], b0[o], u0, 0, 0, 0);
+                        if (two) u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[o], b1[o], u1, 0, 0, 0);
+                    }
+                    double *d0 = S + blk_off(rb0, cb0), *d1 = S + blk_off(rb1, cb1);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) d0[(lk + 4 * v) * SB + lr] -= u0[v];
+                    if (two) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) d1[(lk + 4 * v) * SB + lr] -= u1[v];
+                    }
                 }
-            if (kb >= 1) {  // column kb of X for the owned rows above the diagonal
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-                    if (xrow[i] >= 0 && xrow[i] < kb) {
-                        const int rb = xrow[i];
-                        f64x4 t = {0.0, 0.0, 0.0, 0.0};
-                        for (int k = rb; k < kb; ++k) mfma_nn(t, S + blk_off(rb, k), SB, S + blk_off(k, kb), SB, lr, lk);
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) scratch[(lk + 4 * v) * TS + lr] = t[v];
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        f64x4 x = {0.0, 0.0, 0.0, 0.0};
-                        mfma_nn(x, scratch, TS, dblk, SB, lr, lk);
-                        pend[i] = -x;
-                        __builtin_amdgcn_wave_barrier();
-                    }
             }
+            if (kb >= 1) {  // column kb of X for the owned rows above the diagonal
+                if (xrow[0] >= 0 && xrow[0] < kb) pend[0] = x_entry(xt0, xrow[0], kb, S, dblk, lr, lk);
+                if (xrow[1] >= 0 && xrow[1] < kb) pend[1] = x_entry(xt1, xrow[1], kb, S, dblk, lr, lk);
+                if (ONE && xrow[2] >= 0 && xrow[2] < kb) pend[2] = x_entry(xt2, xrow[2], kb, S, dblk, lr, lk);
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     {  // last column of X
 #pragma unroll
         for (int i = 0; i < 3; ++i)
             if (xrow[i] >= 0 && xrow[i] < nsb - 1) {
                 double *dst = S + blk_off(xrow[i], nsb - 1);
+                const f64x4 xs = frag_transpose(pend[i], lr, lk);
 #pragma unroll
-                for (int v = 0; v < 4; ++v) dst[(lk + 4 * v) * SB + lr] = pend[i][v];
+                for (int v = 0; v < 4; ++v) dst[(lk + 4 * v) * SB + lr] = xs[v];
             }
     }
     __syncthreads();
