@@ -144,6 +144,41 @@ int main() {
             report("(f) A: [publish kernel, kernel that polls B's flag]; B: [gate kernel, setflag]  (2 boundaries)", ms);
             printf("    (f) spin timeouts: %d\n", timeouts);
         }
+        // (g) as (f), but B's hand-backs are stream memory operations of the command processor instead of one-lane kernels:
+        //     g1: setflag -> hipStreamWriteValue32;  g2: also gate -> hipStreamWaitValue32 (>=)
+        for (int mode = 1; mode <= 2; ++mode) {
+            CK(hipMemsetAsync(flags, 0, 64 * sizeof(int), A));
+            CK(hipStreamSynchronize(A));
+            CK(hipEventRecord(t0, A));
+            hipError_t err = hipSuccess;
+            for (int i = 0; i < REPS && err == hipSuccess; ++i) {
+                hipLaunchKernelGGL(busy_publish, dim3(1), dim3(64), 0, A, 0ull, flags + 8, i + 1);
+                hipLaunchKernelGGL(busy_then_poll, dim3(1), dim3(64), 0, A, ticks, flags + 16, i + 1, flags + 24);
+                if (mode == 2)
+                    err = hipStreamWaitValue32(B, flags + 8, i + 1, hipStreamWaitValueGte, 0xFFFFFFFFu);
+                else
+                    hipLaunchKernelGGL(gate, dim3(1), dim3(64), 0, B, flags + 8, i + 1, flags + 24);
+                if (err == hipSuccess) err = hipStreamWriteValue32(B, flags + 16, i + 1, 0);
+            }
+            if (err != hipSuccess) {
+                printf("(g%d) stream memory op refused: %s\n", mode, hipGetErrorString(err));
+                hipLaunchKernelGGL(setflag, dim3(1), dim3(1), 0, B, flags + 16, REPS + 1);  // let A drain
+                CK(hipStreamSynchronize(A));
+                CK(hipStreamSynchronize(B));
+                continue;
+            }
+            CK(hipEventRecord(t1, A));
+            CK(hipStreamSynchronize(A));
+            CK(hipStreamSynchronize(B));
+            CK(hipEventElapsedTime(&ms, t0, t1));
+            int to2 = 0;
+            CK(hipMemcpy(&to2, flags + 24, sizeof(int), hipMemcpyDeviceToHost));
+            if (round) {
+                report(mode == 1 ? "(g1) as (f) with hipStreamWriteValue32 in place of the setflag kernel  (2 boundaries)"
+                                 : "(g2) ... and hipStreamWaitValue32 in place of the gate kernel  (2 boundaries)", ms);
+                printf("    (g%d) spin timeouts: %d\n", mode, to2);
+            }
+        }
     }
     return 0;
 }
