@@ -683,25 +683,30 @@ __device__ __forceinline__ f64x4 frag_transpose(const f64x4 &a, int lr, int lk) 
     return d;
 }
 
+// `tacc` carries the sum one step ahead: the terms k <= kb-2 of column kb only need blocks that were final a step earlier, so
+// step kb-1 accumulates them (the other waves have slack there; in the last step, when wave 0 has nothing left to do, a row's
+// whole sum used to be on the critical path: 5.5 K cycles) and step kb adds the term k = kb-1 and applies W_kk — the same
+// terms in the same order.
 template <int L>
-__device__ __forceinline__ f64x4 x_entry(f64x4 (&xt)[L], int rb, int kb, const double *S, const double *dblk, int lr, int lk) {
+__device__ __forceinline__ f64x4 x_entry(f64x4 (&xt)[L], f64x4 &tacc, int rb, int kb, int nsb, const double *S, const double *dblk,
+                                         int lr, int lk) {
+    auto term = [&](f64x4 &t, int k, int col, const f64x4 &xf) {  // t += U[k,col]' X[rb,k]'
+        const double *ub = S + blk_off(k, col);
+#pragma unroll
+        for (int kk = 0; kk < SB / 4; ++kk) t = __builtin_amdgcn_mfma_f64_16x16x4f64(ub[(kk * 4 + lk) * SB + lr], xf[kk], t, 0, 0, 0);
+    };
     if (kb == rb + 1) {  // X[rb,rb] = W_rb (factor16 left it in S, row-major): read k-major, turned in registers
         const double *w = S + blk_off(rb, rb);
         f64x4 wk;
 #pragma unroll
         for (int v = 0; v < 4; ++v) wk[v] = w[(lk + 4 * v) * SB + lr];
         xt[0] = frag_transpose(wk, lr, lk);
+        tacc = (f64x4){0.0, 0.0, 0.0, 0.0};
     }
-    f64x4 t = {0.0, 0.0, 0.0, 0.0};
+    f64x4 t = tacc;  // terms k = rb .. kb-2
 #pragma unroll
-    for (int d = 0; d < L; ++d) {
-        const int k = rb + d;
-        if (k < kb) {  // wave-uniform (MFMA ignores EXEC)
-            const double *ub = S + blk_off(k, kb);
-#pragma unroll
-            for (int kk = 0; kk < SB / 4; ++kk) t = __builtin_amdgcn_mfma_f64_16x16x4f64(ub[(kk * 4 + lk) * SB + lr], xt[d][kk], t, 0, 0, 0);
-        }
-    }
+    for (int d = 0; d < L; ++d)
+        if (rb + d == kb - 1) term(t, kb - 1, kb, xt[d]);  // wave-uniform (MFMA ignores EXEC)
     f64x4 x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int kk = 0; kk < SB / 4; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(dblk[(kk * 4 + lk) * SB + lr], t[kk], x, 0, 0, 0);
@@ -709,6 +714,13 @@ __device__ __forceinline__ f64x4 x_entry(f64x4 (&xt)[L], int rb, int kb, const d
 #pragma unroll
     for (int d = 1; d < L; ++d)
         if (rb + d == kb) xt[d] = x;
+    if (kb + 1 < nsb) {  // column kb+1: its terms k = rb .. kb-1
+        f64x4 tn = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int d = 0; d < L; ++d)
+            if (rb + d < kb) term(tn, rb + d, kb + 1, xt[d]);
+        tacc = tn;
+    }
     return x;
 }
 
@@ -823,7 +835,7 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
     // Wave 0 and waves 1-3 run the loop as two separate code regions (same barriers, two per step, in both): the elimination's
     // registers and the X rows the other waves keep in registers then never coexist in one wave's allocation.
     if (wave_u == 0) {
-        f64x4 xw[2];  // row nsb - 2 of X from the diagonal on (full tiles only)
+        f64x4 xw[2], tw;  // row nsb - 2 of X from the diagonal on (full tiles only)
         for (int kb = 0; kb < nsb; ++kb) {
             double *dblk = S + blk_off(kb, kb);  // W_kk
             phase_b(kb, dblk);
@@ -839,12 +851,13 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
                 __builtin_amdgcn_wave_barrier();
                 factor16(dst, lane, (kb + 1) * SB, logsum, bad);
             } else if (!ONE) {  // last step: nothing left to eliminate — the one entry of X's row 6
-                pend[0] = x_entry(xw, xrow[0], kb, S, dblk, lr, lk);
+                pend[0] = x_entry(xw, tw, xrow[0], kb, nsb, S, dblk, lr, lk);
             }
             __syncthreads();
         }
     } else {
         f64x4 xt0[7], xt1[4], xt2[ONE ? 2 : 1];  // the owned rows' blocks from the diagonal on (rows {0,1,2} | {3,4,5,6} | {5})
+        f64x4 ta0, ta1, ta2;                      // ... and their next column's sum so far
         for (int kb = 0; kb < nsb; ++kb) {
             double *dblk = S + blk_off(kb, kb);  // W_kk
             phase_b(kb, dblk);
@@ -896,9 +909,9 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
                 }
             }
             if (kb >= 1) {  // column kb of X for the owned rows above the diagonal
-                if (xrow[0] >= 0 && xrow[0] < kb) pend[0] = x_entry(xt0, xrow[0], kb, S, dblk, lr, lk);
-                if (xrow[1] >= 0 && xrow[1] < kb) pend[1] = x_entry(xt1, xrow[1], kb, S, dblk, lr, lk);
-                if (ONE && xrow[2] >= 0 && xrow[2] < kb) pend[2] = x_entry(xt2, xrow[2], kb, S, dblk, lr, lk);
+                if (xrow[0] >= 0 && xrow[0] < kb) pend[0] = x_entry(xt0, ta0, xrow[0], kb, nsb, S, dblk, lr, lk);
+                if (xrow[1] >= 0 && xrow[1] < kb) pend[1] = x_entry(xt1, ta1, xrow[1], kb, nsb, S, dblk, lr, lk);
+                if (ONE && xrow[2] >= 0 && xrow[2] < kb) pend[2] = x_entry(xt2, ta2, xrow[2], kb, nsb, S, dblk, lr, lk);
             }
             __syncthreads();
         }
