@@ -724,6 +724,44 @@ __device__ __forceinline__ f64x4 x_entry(f64x4 (&xt)[L], f64x4 &tacc, int rb, in
     return x;
 }
 
+// Trailing update inside diag_kernel: D[rb,cb] -= U[kb,rb]' U[kb,cb] for Q blocks of a wave's list (entries i0, i0 + 3, ... of
+// the row-major list of the trailing sub-blocks after (kb+1, kb+1); n = trailing block rows): Q independent MFMA chains
+// interleaved, the destination blocks requested before the products.
+template <int Q>
+__device__ __forceinline__ void c_group(double *S, int kb, int n, int i0, int lr, int lk) {
+    const double *a[Q], *b[Q];
+    double *dd[Q];
+#pragma unroll
+    for (int qq = 0; qq < Q; ++qq) {
+        int r = 0, rem = i0 + 3 * qq + 1;  // + 1: the list starts after (kb+1, kb+1)
+        while (rem >= n - r) {
+            rem -= n - r;
+            ++r;
+        }
+        const int rb = kb + 1 + r, cb = rb + rem;
+        a[qq] = S + blk_off(kb, rb);
+        b[qq] = S + blk_off(kb, cb);
+        dd[qq] = S + blk_off(rb, cb);
+    }
+    f64x4 u[Q], dv[Q];
+#pragma unroll
+    for (int qq = 0; qq < Q; ++qq) {
+        u[qq] = (f64x4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) dv[qq][v] = dd[qq][(lk + 4 * v) * SB + lr];
+    }
+#pragma unroll
+    for (int kk = 0; kk < SB / 4; ++kk) {
+        const int o = (kk * 4 + lk) * SB + lr;
+#pragma unroll
+        for (int qq = 0; qq < Q; ++qq) u[qq] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[qq][o], b[qq][o], u[qq], 0, 0, 0);
+    }
+#pragma unroll
+    for (int qq = 0; qq < Q; ++qq)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) dd[qq][(lk + 4 * v) * SB + lr] = dv[qq][v] - u[qq][v];
+}
+
 // nkb: trailing block rows of U still to be applied to the stored diagonal tile, D = P - sum_{j-nkb <= k < j} U[k,j]'U[k,j]
 // (1 in the plain schedule, 2 in the pipelined one, 0 for j == 0).
 // want_g (pipelined schedule): also rows 0..127 of Mats::W := -U[j-1,j] W_j, the dense half of solve_kernel<1>'s left operand.
@@ -873,40 +911,15 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
                     }
             }
             {  // (C), all but the next diagonal sub-block: block p of the row-major list goes to wave p % 3 + 1, which takes its
-               // blocks two at a time — two independent MFMA chains interleaved (one at a time: ~960 cycles per block, and the
-               // first sub-block steps waited for these waves)
+               // blocks three at a time (c_group: independent MFMA chains interleaved; one block at a time cost ~960 cycles each,
+               // and the first sub-block steps waited for these waves), then the two or one left over
                 const int n = nsb - 1 - kb, total = n * (n + 1) / 2 - 1;
-                auto decode = [&](int idx, int &rb, int &cb) {
-                    int r = 0, rem = idx + 1;  // + 1: the list starts after (kb+1, kb+1)
-                    while (rem >= n - r) {
-                        rem -= n - r;
-                        ++r;
-                    }
-                    rb = kb + 1 + r;
-                    cb = rb + rem;
-                };
-                for (int i0 = wave_u - 1; i0 < total; i0 += 6) {
-                    int rb0, cb0, rb1, cb1;
-                    decode(i0, rb0, cb0);
-                    const bool two = i0 + 3 < total;
-                    decode(two ? i0 + 3 : i0, rb1, cb1);
-                    const double *a0 = S + blk_off(kb, rb0), *b0 = S + blk_off(kb, cb0);
-                    const double *a1 = S + blk_off(kb, rb1), *b1 = S + blk_off(kb, cb1);
-                    f64x4 u0 = {0.0, 0.0, 0.0, 0.0}, u1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int kk = 0; kk < SB / 4; ++kk) {
-                        const int o = (kk * 4 + lk) * SB + lr;
-                        u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[o], b0[o], u0, 0, 0, 0);
-                        if (two) u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[o], b1[o], u1, 0, 0, 0);
-                    }
-                    double *d0 = S + blk_off(rb0, cb0), *d1 = S + blk_off(rb1, cb1);
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) d0[(lk + 4 * v) * SB + lr] -= u0[v];
-                    if (two) {
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) d1[(lk + 4 * v) * SB + lr] -= u1[v];
-                    }
-                }
+                int i0 = wave_u - 1;
+                for (; i0 + 6 < total; i0 += 9) c_group<3>(S, kb, n, i0, lr, lk);
+                if (i0 + 3 < total)
+                    c_group<2>(S, kb, n, i0, lr, lk);
+                else if (i0 < total)
+                    c_group<1>(S, kb, n, i0, lr, lk);
             }
             if (kb >= 1) {  // column kb of X for the owned rows above the diagonal
                 if (xrow[0] >= 0 && xrow[0] < kb) pend[0] = x_entry(xt0, ta0, xrow[0], kb, nsb, S, dblk, lr, lk);
