@@ -1680,6 +1680,13 @@ constexpr int SPLITK_MAX = BARK_SPLITK_MAX;
 // of MFMA work).  Measured (448 | 384 vs 512 everywhere): N = 16384 lone 30.2 -> 28.7 ms, N = 8192 x 2 10.7 -> 9.4,
 // N = 4096 x 8 5.59 -> 5.2.
 constexpr int LA_SLOTS = BARK_LA_SLOTS, LA_SLOTS_CHAIN = BARK_LA_SLOTS_CHAIN;
+// ... of an under-filled bulk launch of the pipelined schedule (two are in flight, and the chain kernels need slots beside
+// them): same box, 384 | 448 | 320 | 512 — N = 4096 x 8 4.29 | 4.42 | 4.30 | 4.56 ms, x 16 6.98 | 7.07 | 7.11 | 7.13,
+// N = 8192 x 2 7.99 | 8.25 | 8.04 | 8.46, N = 16384 x 1 25.4 | 25.6 | 26.4 | 25.9
+#ifndef BARK_PIPE_BULK_SLOTS
+#define BARK_PIPE_BULK_SLOTS 384
+#endif
+constexpr int PIPE_BULK_SLOTS = BARK_PIPE_BULK_SLOTS;
 constexpr long LA_BULK_WORK = BARK_LA_BULK_WORK;
 // slabs (128 x 128) of one set: a split step has fewer than SPLITK_SLOTS / 2 tiles x matrices, each with S slabs
 // (tiles x matrices x S <= the slots aimed at) plus one for the last block row
@@ -2168,7 +2175,7 @@ struct Sweep {
         const int k = kdone(j), nt = tiles_of(j);
         int S = 1;
         if (k >= 2 && nt * p.Bc < SPLITK_SLOTS / 2) {
-            S = (2 * LA_SLOTS + nt * p.Bc) / (2 * nt * p.Bc);
+            S = (2 * PIPE_BULK_SLOTS + nt * p.Bc) / (2 * nt * p.Bc);
             if (S > k) S = k;
             if (S > SPLITK_MAX) S = SPLITK_MAX;
             while (S > 1 && S * nt * p.Bc > SPLITK_SLOTS) --S;
