@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Tuning build with s_memtime stamps in diag_kernel -> tools/ab/stamps.so (never the product; the product sources carry
+"""HISTORIC: the text anchors below match diag_kernel as it was up to the middle of round 3 (git show 6b1c09b:bark_amd/csrc/chol.hip);
+against the current sources use tools/ab/make_stamps2.py / stamps2.py (coarse stamps, which do not perturb the kernel).
+Tuning build with s_memtime stamps in diag_kernel -> tools/ab/stamps.so (never the product; the product sources carry
 no stamp code: this script copies bark_amd/csrc to /tmp, inserts the stamps by text anchors, and builds).
    python tools/ab/make_stamps.py && (on the GPU box) python tools/ab/stamps.py"""
 import os, re, shutil, subprocess, sys
