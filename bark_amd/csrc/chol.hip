@@ -1019,6 +1019,13 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
             }
         }
         if (code != 0 && (info_in == 0 || code == -3)) p.info[b] = code;
+        if (ob.mll) {  // last block step of an MLL-only sweep: finish_mll_kernel's arithmetic here, one launch less
+            if (*ob.fault) p.info[b] = -1;
+            if (p.sync && __hip_atomic_load(p.sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) p.info[b] = -3;
+            double v = -(acc_quad + (red[0] + red[1])) - (acc_logdet + 2.0 * logsum);
+            if (ob.include_2pi) v = v - (double)p.N * log(2.0 * M_PI);
+            ob.mll[b] = 0.5 * v;
+        }
     }
 }
 
@@ -1866,6 +1873,11 @@ struct Sweep {
     // (device-side progress counter) instead of an event wait on the caller's stream; see diag_kernel
     bool dev_wait = false;
     bool pre_update = false;  // ... and the rank-128 / 256 update of the diagonal tile runs as diag_pre_kernel
+    // MLL-only sweeps: the last diag_kernel launch of the chunk writes the MLL itself (fin_mll != nullptr); `finished` says it did
+    double *fin_mll = nullptr;
+    const int32_t *fin_fault = nullptr;
+    int fin_2pi = 0;
+    bool finished = false;
     bool dev_gate = false;  // ... and the helper streams are released by gate kernels instead of an event record
     int rep = 0;
     double *slabs = nullptr;
@@ -1940,8 +1952,11 @@ struct Sweep {
             nkb = 0;
             publish = 0;
         }
+        // the last block step of an MLL-only sweep also writes the MLL (no row launch left to wait for there: wait_slot < 0)
+        const OneBlock fin = (fin_mll && j == nrb_steps - 1 && wait_slot < 0) ? OneBlock{nullptr, fin_mll, fin_fault, fin_2pi, rep} : OneBlock{};
+        if (fin.mll) finished = true;
         hipLaunchKernelGGL(diag_kernel<false>, dim3((unsigned)p.Bc), dim3(THREADS), exclusive ? DIAG_LDS_EXCLUSIVE : DIAG_LDS, main, p, j, nkb,
-                           want_g, wait_slot, wait_value, OneBlock{}, publish);
+                           want_g, wait_slot, wait_value, fin, publish);
         BARK_LAUNCH_CHECK();
         return mark_on(main);
     }
@@ -2422,9 +2437,11 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
     auto epilogue = [&](int64_t c0, int64_t bc) -> int {  // MLL and posterior reductions of one chunk
         Mats &p = sw.p;
         hipStream_t s = sw.main;
-        hipLaunchKernelGGL(finish_mll_kernel, dim3((unsigned)((bc + 255) / 256)), dim3(256), 0, s, p.accum, (int)bc, (int)N,
-                           (flags & BARK_MLL_INCLUDE_2PI) ? 1 : 0, mll_out + c0, ctx->fault, p.info, sw.dev_wait ? p.sync : nullptr);
-        BARK_LAUNCH_CHECK();
+        if (!sw.finished) {
+            hipLaunchKernelGGL(finish_mll_kernel, dim3((unsigned)((bc + 255) / 256)), dim3(256), 0, s, p.accum, (int)bc, (int)N,
+                               (flags & BARK_MLL_INCLUDE_2PI) ? 1 : 0, mll_out + c0, ctx->fault, p.info, sw.dev_wait ? p.sync : nullptr);
+            BARK_LAUNCH_CHECK();
+        }
         if (C > 0) {
             const int prc = launch_predict_reduce(p, (int)N, (int)C, (int)bc, rhs_identity ? nullptr : scale + c0,
                                                   mu_out + (size_t)c0 * C, var_out ? var_out + (size_t)c0 * C : nullptr,
@@ -2485,6 +2502,10 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
         // N = 2048 x 4 1.082 | 1.125; in the pipelined schedule the extra launch queues for slots behind the resident row
         // workgroups like every kernel of the chain does (N = 4096 x 8 4.77 | 4.46, x 16 7.61 | 7.11, N = 16384 x 1 27.2 | 25.4)
         sw.pre_update = splitk && bc <= DEVWAIT_MAX_BC;
+        sw.finished = false;
+        sw.fin_mll = (C == 0 && !timing) ? mll_out + c0 : nullptr;
+        sw.fin_fault = ctx->fault;
+        sw.fin_2pi = (flags & BARK_MLL_INCLUDE_2PI) ? 1 : 0;
         if ((rc = prologue(c0, bc))) return rc;
         for (int j = 0; j < nrb; ++j)
             if ((rc = sw.step(j))) return rc;
