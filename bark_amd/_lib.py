@@ -47,6 +47,7 @@ SIGNATURES = {
     "bark_version": (ci, []),
     "bark_last_error": (ctypes.c_char_p, []),
     "bark_device_wait": (ci, [ci]),
+    "bark_xcd_map_selftest": (ci, [ci, ci]),
     "bark_comm_unique_id": (ci, [vp]),
     "bark_comm_create": (ci, [vp, ci, ci, ci, ctypes.POINTER(vp)]),
     "bark_comm_destroy": (None, [vp]),

@@ -247,8 +247,17 @@ __device__ __forceinline__ void gemm_upper_tri(f64x4 (&acc)[4][4], const int (&r
 // R = ceil(8 / Bc) "virtual matrices" holding every R-th tile; virtual matrix v goes to XCD v % 8.
 // Grid = 8 * ceil(Bc R / 8) * ceil(ntiles / R); ids that fall outside exit.
 constexpr int NXCD = 8;
-__host__ __device__ __forceinline__ int xcd_rep(int Bc) { return Bc >= NXCD ? 1 : (NXCD + Bc - 1) / Bc; }
-__device__ __forceinline__ bool xcd_map(int id, int ntiles, int Bc, int &b, int &tile) {
+// ... and so would a chunk size that is not a multiple of 8 while it is small (12 matrices: four XCDs with two, four with one —
+// the launch took as long as 16: N = 4096 x 9 / 12 / 16 ran 6.1 / 7.0 / 7.2 ms): then R = 8 / gcd(Bc, 8) virtual matrices per
+// matrix make Bc R a multiple of 8 (4.9 / 5.9 / 7.2 ms).  From 10 % imbalance down (Bc > 72) the locality of one matrix per XCD
+// is worth more.
+__host__ __device__ __forceinline__ int xcd_rep(int Bc) {
+    if (Bc < NXCD) return (NXCD + Bc - 1) / Bc;
+    const int rounds = (Bc + NXCD - 1) / NXCD;
+    if (Bc % NXCD == 0 || rounds * NXCD * 10 < Bc * 11) return 1;
+    return (Bc % 4 == 0) ? 2 : (Bc % 2 == 0) ? 4 : 8;
+}
+__host__ __device__ __forceinline__ bool xcd_map(int id, int ntiles, int Bc, int &b, int &tile) {
     const int R = xcd_rep(Bc), ntv = (ntiles + R - 1) / R;
     const int x = id % NXCD, q = id / NXCD;
     const int v = (q / ntv) * NXCD + x;  // virtual matrix
@@ -256,7 +265,7 @@ __device__ __forceinline__ bool xcd_map(int id, int ntiles, int Bc, int &b, int 
     tile = (q % ntv) * R + (v - b * R);
     return b < Bc && tile < ntiles;
 }
-inline unsigned xcd_grid(int ntiles, int Bc) {
+__host__ __device__ inline unsigned xcd_grid(int ntiles, int Bc) {
     const int R = xcd_rep(Bc), ntv = (ntiles + R - 1) / R;
     return (unsigned)(NXCD * ((Bc * R + NXCD - 1) / NXCD) * ntv);
 }
@@ -2303,6 +2312,19 @@ std::atomic<bool> &device_wait_enabled() {
 }  // namespace bark
 
 extern "C" {
+
+int bark_xcd_map_selftest(int ntiles, int Bc) {
+    if (ntiles < 1 || Bc < 1) return -1;
+    std::vector<int> hits((size_t)ntiles * Bc, 0);
+    const unsigned grid = bark::xcd_grid(ntiles, Bc);
+    for (unsigned id = 0; id < grid; ++id) {
+        int b, t;
+        if (bark::xcd_map((int)id, ntiles, Bc, b, t)) ++hits[(size_t)b * ntiles + t];
+    }
+    int wrong = 0;
+    for (int h : hits) wrong += h != 1;
+    return wrong;
+}
 
 int bark_device_wait(int on) {
     const bool prev = device_wait_enabled().exchange(on != 0);

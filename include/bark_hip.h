@@ -62,6 +62,10 @@ const char *bark_last_error(void);
  * where they cannot (every stream of the process serialised onto one hardware queue), the wait times out and the call
  * reports info_out[b] = -3: switch it off and call again.  Never used under stream capture. */
 int bark_device_wait(int on);
+/* Host-side self-check of the workgroup -> (matrix, tile) map the sweep kernels share (XCD-aware placement: speed only, but a
+ * map that skipped or doubled a pair would be a wrong result): 0 when the launch grid of `ntiles` tiles x `Bc` matrices
+ * reaches every pair exactly once, else the number of pairs missed or reached twice.  No GPU needed. */
+int bark_xcd_map_selftest(int ntiles, int Bc);
 
 /* ---------------------------------------------------------------------------------------
  * Context — replaces nothing in the reference (pure functions on numpy arrays, forest.py:58-111); it is where the

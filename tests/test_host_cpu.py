@@ -315,3 +315,16 @@ def test_context_api_without_a_gpu_fails_with_a_status_not_a_crash():
     assert b"bark_ctx" in lib.bark_last_error()
     assert lib.bark_mll_batched_hip(None, None, None, None, 1, 1, None, None, None, None, 0, None, 0, None, None, None, None, None,
                                     None, 0, 1, None, None) == _lib.BARK_ERR_ARG
+
+
+def test_workgroup_to_tile_map_reaches_every_pair_once():
+    """The sweep kernels share one workgroup -> (matrix, tile) map (XCD-aware placement, chol.hip xcd_map): chunks smaller than 8
+    matrices, and small chunks whose size is not a multiple of 8, are dealt out as "virtual matrices" so that no XCD carries
+    twice the work of another.  Placement is speed only — but the map has to be a bijection onto the launch's pairs."""
+    from bark_amd import _lib
+
+    lib = _lib.lib()
+    for Bc in list(range(1, 81)) + [96, 100, 250, 256, 1000]:
+        for ntiles in (1, 2, 3, 7, 8, 15, 31, 32, 100, 248):
+            assert lib.bark_xcd_map_selftest(ntiles, Bc) == 0, (ntiles, Bc)
+    assert lib.bark_xcd_map_selftest(0, 4) == -1
