@@ -312,7 +312,6 @@ __device__ __forceinline__ double *w_block(const Mats &p, int b) { return p.W + 
 // ---------------------------------------------------------------------------------------------
 constexpr int SB = 16;          // sub-block edge
 constexpr int NSB = NB / SB;    // 8 sub-blocks per edge
-constexpr int TS = SB + 1;      // row stride of the per-wave 16x16 transpose scratch
 constexpr int NBLK = NSB * (NSB + 1) / 2;  // 36 stored sub-blocks (upper block triangle)
 constexpr int NSB_ROWS = NSB;             // 16-row tiles per block (y-update partials)
 
@@ -805,7 +804,7 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
     const int info_in = (tid == 0 && !one) ? p.info[b] : 0;
 
     double *S = lds;                                          // packed upper block triangle, NBLK x [16][16]
-    double *vec = lds + NBLK * SB * SB + 4 * SB * TS;         // [2][128] y | upper-half partial sums
+    double *vec = lds + NBLK * SB * SB;                       // [2][128] y | upper-half partial sums
     double *red = vec + 2 * NB;                               // [8]
     uint32_t *codes = nullptr;
     if (one) {  // the matrix's leaf codes (nW x 128 dwords) behind everything else in LDS
@@ -1808,7 +1807,9 @@ Layout make_layout(int64_t N, int64_t C, int64_t m, int64_t Bc) {
     return L;
 }
 
-constexpr size_t DIAG_LDS = (size_t)(NBLK * SB * SB + 4 * SB * TS + 2 * NB + 8) * sizeof(double);
+// (74.3 KiB: two of these workgroups fit a CU — chunks of more than 256 small matrices — or one beside a row workgroup; the four
+// per-wave transpose scratch blocks that used to sit between the factor image and `vec` went with x_entry)
+constexpr size_t DIAG_LDS = (size_t)(NBLK * SB * SB + 2 * NB + 8) * sizeof(double);
 // With few matrices resident the diag workgroup IS the critical path of the sweep, and a split-K / row workgroup that
 // lands on its CU stretches it from 52 to 62-77 us (kernel timeline of a lone N = 4096 matrix).  Asking for the whole
 // 160 KiB of LDS keeps the CU to itself (lone N = 4096: 2.83 -> 2.59 ms; neutral from 8 matrices on, harmful at 64:
