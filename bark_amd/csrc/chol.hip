@@ -244,18 +244,18 @@ __device__ __forceinline__ void gemm_upper_tri(f64x4 (&acc)[4][4], const int (&r
 // one matrix streams the same A panel U[0:128j, j]: give all tiles of matrix b ids == b (mod 8), in one
 // contiguous run of the per-XCD sequence, so that panel is fetched into ONE 4 MiB L2 once and shared.
 // With fewer than 8 resident matrices that would leave XCDs idle, so each matrix is split into
-// R = ceil(8 / Bc) "virtual matrices" holding every R-th tile; virtual matrix v goes to XCD v % 8.
+// R "virtual matrices" holding every R-th tile; virtual matrix v goes to XCD v % 8 (R: xcd_rep — Bc R is a multiple of 8).
 // Grid = 8 * ceil(Bc R / 8) * ceil(ntiles / R); ids that fall outside exit.
 constexpr int NXCD = 8;
 // ... and so would a chunk size that is not a multiple of 8 while it is small (12 matrices: four XCDs with two, four with one —
 // the launch took as long as 16: N = 4096 x 9 / 12 / 16 ran 6.1 / 7.0 / 7.2 ms): then R = 8 / gcd(Bc, 8) virtual matrices per
 // matrix make Bc R a multiple of 8 (4.9 / 5.9 / 7.2 ms).  From 10 % imbalance down (Bc > 72) the locality of one matrix per XCD
-// is worth more.
+// is worth more.  The same for 3, 5, 6, 7 matrices, which used to get ceil(8 / Bc) virtual matrices each — 9, 10, 12, 14 on 8 XCDs
+// (N = 8192 x 3 14.2 -> 10.5 ms, N = 4096 x 5 / 6 4.10 / 4.33 -> 3.44 / 3.59).
 __host__ __device__ __forceinline__ int xcd_rep(int Bc) {
-    if (Bc < NXCD) return (NXCD + Bc - 1) / Bc;
     const int rounds = (Bc + NXCD - 1) / NXCD;
-    if (Bc % NXCD == 0 || rounds * NXCD * 10 < Bc * 11) return 1;
-    return (Bc % 4 == 0) ? 2 : (Bc % 2 == 0) ? 4 : 8;
+    if (Bc % NXCD == 0 || (Bc > NXCD && rounds * NXCD * 10 < Bc * 11)) return 1;
+    return (Bc % 4 == 0) ? 2 : (Bc % 2 == 0) ? 4 : 8;  // 8 / gcd(Bc, 8); fewer than 8 matrices: 3, 5, 6, 7 of them used to get ceil(8 / Bc)
 }
 __host__ __device__ __forceinline__ bool xcd_map(int id, int ntiles, int Bc, int &b, int &tile) {
     const int R = xcd_rep(Bc), ntv = (ntiles + R - 1) / R;
