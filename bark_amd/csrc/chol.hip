@@ -1706,8 +1706,11 @@ constexpr long LA_BULK_WORK = BARK_LA_BULK_WORK;
 // slabs (128 x 128) of one set: a split step has fewer than SPLITK_SLOTS / 2 tiles x matrices, each with S slabs
 // (tiles x matrices x S <= the slots aimed at) plus one for the last block row
 constexpr size_t SLAB_SET_TILES = (LA_SLOTS > SPLITK_SLOTS ? LA_SLOTS : SPLITK_SLOTS) + SPLITK_SLOTS / 2;
+// look-ahead from this much bulk work on ((tiles x matrices) x block rows; see Sweep::lookahead).  Re-measured with this round's
+// shorter chain, same box, 450 | 600: N = 4096 x 2 2.28 | 2.45 ms, N = 6000 x 1 3.27 | 3.64, N = 5600 x 1 3.07 | 3.18, nothing
+// else moves; from 200 down the lone N = 4096 matrix and N = 2048 x 4 get look-ahead steps and lose 7-15 %
 #ifndef BARK_LA_MIN_WORK
-#define BARK_LA_MIN_WORK 600
+#define BARK_LA_MIN_WORK 450
 #endif
 constexpr long LA_MIN_WORK = BARK_LA_MIN_WORK;
 #ifndef BARK_TAIL_MAX_WGS
