@@ -2318,7 +2318,7 @@ std::atomic<bool> &device_wait_enabled() {
 extern "C" {
 
 int bark_xcd_map_selftest(int ntiles, int Bc) {
-    if (ntiles < 1 || Bc < 1) return -1;
+    if (ntiles < 1 || Bc < 1 || (long)ntiles * Bc > (1L << 26)) return -1;
     std::vector<int> hits((size_t)ntiles * Bc, 0);
     const unsigned grid = bark::xcd_grid(ntiles, Bc);
     for (unsigned id = 0; id < grid; ++id) {
