@@ -204,6 +204,18 @@ def test_mixed_types_and_ragged_sizes_against_oracle(B):
         assert np.allclose(got, want, rtol=MLL_RTOL, atol=MLL_ATOL), (N, got, want)
 
 
+def test_gram_with_odd_row_lengths(B):
+    """An N x M output with odd M has every other row starting 8 bytes off a 16-byte boundary (and, with odd N M, every other
+    forest too): gram_kernel writes those rows as shifted pairs (gram.hip).  Bit-exact against the oracle, sizes on both sides
+    of the 64- and 128-column tile edges."""
+    for N, M in ((5, 257), (9, 127), (64, 255), (33, 1), (2, 3), (257, 385), (130, 129)):
+        X, _, bounds, ft = B.syn.mixed_problem(N, seed=7 * N + M)
+        X2 = B.syn.mixed_problem(M, seed=11 * M + N)[0]
+        F = B.syn.sample_prior_forests(3, 21, bounds, ft, seed=N + M)
+        assert np.array_equal(B.bf.batched_forest_gram_matrix(F, X, X2, ft), B.orc.batched_forest_gram_matrix(F, X, X2, ft)), (N, M)
+        assert np.array_equal(B.bf.forest_gram_matrix(F[2], X2, X2, ft), B.orc.forest_gram_matrix(F[2], X2, X2, ft)), M
+
+
 def test_deep_trees_and_many_leaves(B):
     rng = np.random.default_rng(5)
     X = rng.uniform(size=(300, 6))
