@@ -825,6 +825,9 @@ def extras(args, wl, result, mll_host):
         entry("c4 per-GPU share: N=4096, 64 forests", Workload(4096, d, m, 64, N, 0), 5)
         entry("small batch: N=4096, 16 forests", Workload(4096, d, m, 16, N, 0), 5)
         entry("small batch: N=4096, 8 forests", Workload(4096, d, m, 8, N, 0), 5)
+        # batch sizes off the multiples of 8 (the number of XCDs: the workgroup -> tile map deals them out as virtual matrices)
+        entry("small batch: N=4096, 12 forests", Workload(4096, d, m, 12, N, 0), 5)
+        entry("small batch: N=4096, 5 forests", Workload(4096, d, m, 5, N, 0), 5)
         entry("lone matrix: N=4096, 1 forest", Workload(4096, d, m, 1, N, 0), 10, graph=True)
         # the regime the reference itself runs in (BO with tens to hundreds of points: BASELINE configs[0] is N = 64)
         for n_small in (64, 256, 512):
