@@ -191,7 +191,9 @@ constexpr int CS_FIN_ROWS = 16;  // rows of Y per colsum_finish_kernel workgroup
 
 // rows of K per workgroup: 128 up to N = 4096 (1024 workgroups there; fewer, longer ones measured slower), growing
 // with N so that at most 32 segment partials are written and summed
-inline int colsum_segment(int64_t N) { return 128 * (int)((N + 4095) / 4096); }
+// ... and shrinking below N = 2048, where the launch is a chain of row batches per wave (latency, not bytes: 128 rows were 15.6 us
+// at N = 1000 for 8 MB) — 32 rows up to N = 1024, 64 up to 2048: still at most 32 partials
+inline int colsum_segment(int64_t N) { return N <= 1024 ? 32 : N <= 2048 ? 64 : 128 * (int)((N + 4095) / 4096); }
 
 template <int RT>
 __global__ __launch_bounds__(LR_THREADS) void colsum_kernel(const double *__restrict__ K, const double *__restrict__ U,
@@ -342,10 +344,22 @@ __global__ __launch_bounds__(LR_THREADS) void skinny_t_kernel(const double *__re
 // columns carry -1: leaf vectors being removed), Gauss-Jordan with partial pivoting -> den^-1 (written to
 // `inv`, r x r) and log|det den|.  With `dquad`: v = sum of the v shares and dquad = v' den^-1 v (the change of
 // y'K^-1 y).  `logabsdet` / `dquad` may be null.
+// Device-side tree sweeps (bark_tree_sweep_chains_hip) — bound by the HOST's launch rate up to N ~ 1000 (7 us per launch, ten
+// launches per tree proposal) — fold two neighbours into this kernel:
+//   partial != nullptr: the shares are summed here (reduce_shares_kernel's order: a wave per entry, lanes stride the blocks, xor
+//                       butterfly) instead of being read from `sums`;
+//   dec.accept_out != nullptr: the Metropolis decision of decide_kernel, for this chain, once dquad and log|det| are known.
+struct DecideArgs {
+    const double *log_q_prior, *log_u;  // (chains,) of this step
+    double *state;                      // (chains, 2) running y'K^-1 y, log|K|
+    const int32_t *accept_prev;         // previous step's flags or nullptr
+    int32_t *accept_out;                // (chains,) or nullptr: no decision here
+};
 __global__ __launch_bounds__(LR_THREADS) void small_kernel(const double *__restrict__ sums, int r, ChainInts r_negs,
                                                            double *__restrict__ inv,
                                                            double *__restrict__ logabsdet, int *__restrict__ singular,
-                                                           double *__restrict__ dquad, Chain ch, int out_stride) {
+                                                           double *__restrict__ dquad, Chain ch, int out_stride,
+                                                           const double *__restrict__ partial, int nblocks, DecideArgs dec) {
     __shared__ double aug[LR_MAX][2 * LR_MAX + 1];  // [den | I]
     __shared__ double vsh[LR_MAX];
     __shared__ int piv_row;
@@ -356,8 +370,8 @@ __global__ __launch_bounds__(LR_THREADS) void small_kernel(const double *__restr
     if (singular) singular = reinterpret_cast<int *>(reinterpret_cast<double *>(singular) + blockIdx.x * ch.ws);
     if (logabsdet) logabsdet += (size_t)blockIdx.x * out_stride;
     if (dquad) dquad += (size_t)blockIdx.x * out_stride;
-    for (int e = tid; e < r * r + r; e += LR_THREADS) {
-        const double g = sums[e];
+    bool is_singular = false;  // thread 0's view
+    auto place = [&](int e, double g) {  // entry e of the summed shares -> [den | I] and v
         if (e < r * r) {
             const int a = e / r, bcol = e - a * r;
             aug[a][bcol] = g + (a == bcol ? (a < r_neg ? -1.0 : 1.0) : 0.0);
@@ -365,6 +379,19 @@ __global__ __launch_bounds__(LR_THREADS) void small_kernel(const double *__restr
         } else {
             vsh[e - r * r] = g;
         }
+    };
+    if (partial) {
+        partial += blockIdx.x * ch.ws;
+        const int per = r * r + r, lane = tid & 63;
+        for (int e = tid >> 6; e < per; e += LR_THREADS / 64) {
+            double g = 0.0;
+            for (int blk = lane; blk < nblocks; blk += 64) g += partial[(size_t)blk * per + e];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) g += __shfl_xor(g, off);
+            if (lane == 0) place(e, g);
+        }
+    } else {
+        for (int e = tid; e < r * r + r; e += LR_THREADS) place(e, sums[e]);
     }
     __syncthreads();
     double logsum = 0.0;
@@ -378,6 +405,7 @@ __global__ __launch_bounds__(LR_THREADS) void small_kernel(const double *__restr
                     best = a;
                 }
             piv_row = best;
+            if (bv == 0.0) is_singular = true;
             if (bv == 0.0 && singular) *singular = col + 1;
         }
         __syncthreads();
@@ -404,11 +432,26 @@ __global__ __launch_bounds__(LR_THREADS) void small_kernel(const double *__restr
         __syncthreads();
     }
     if (tid == 0 && logabsdet) *logabsdet = logsum;
-    if (tid == 0 && dquad) {
+    if (tid == 0 && (dquad || dec.accept_out)) {
         double q = 0.0;
         for (int a = 0; a < r; ++a)
             for (int b2 = 0; b2 < r; ++b2) q = fma(vsh[a] * aug[a][r + b2], vsh[b2], q);
-        *dquad = q;
+        if (dquad) *dquad = q;
+        if (dec.accept_out) {  // decide_kernel, for chain blockIdx.x
+            const int b = blockIdx.x;
+            int acc;
+            if (is_singular || (dec.accept_prev && dec.accept_prev[b] < 0)) {
+                acc = -1;
+            } else {
+                const double log_alpha = dec.log_q_prior[b] + 0.5 * (q - logsum);
+                acc = (dec.log_u[b] <= fmin(log_alpha, 0.0)) ? 1 : 0;  // NaN compares false: reject
+            }
+            dec.accept_out[b] = acc;
+            if (acc > 0) {
+                dec.state[2 * b] = dec.state[2 * b] - q;
+                dec.state[2 * b + 1] = dec.state[2 * b + 1] + logsum;
+            }
+        }
     }
     if (inv)
         for (int e = tid; e < r * r; e += LR_THREADS) inv[e] = aug[e / r][r + (e - (e / r) * r)];
@@ -437,12 +480,16 @@ __global__ __launch_bounds__(LR_THREADS) void left_factor_kernel(const double *_
 }
 
 // out[i][j] = K[i][j] - sum_a M[i][a] * R[j][a]     (R = Y for symmetric K_inv, else (U'K_inv)')
+// inv != nullptr (device-side sweeps): M is not read — the workgroup forms its 64 rows of M = Y den^-1 itself (left_factor_kernel's
+// arithmetic per entry; Y = the rows of `Yrows`), a launch less per tree proposal.
 __global__ __launch_bounds__(LR_THREADS) void rank_update_kernel(const double *__restrict__ K,
                                                                  const double *__restrict__ M,
                                                                  const double *__restrict__ R, int N, int r,
                                                                  double *__restrict__ out, Chain ch, ChainInts accept,
-                                                                 const int32_t *__restrict__ accept_dev) {
-    extern __shared__ __attribute__((aligned(16))) double strips[];  // Ms[64][r] | Rs[64][r]
+                                                                 const int32_t *__restrict__ accept_dev,
+                                                                 const double *__restrict__ inv,
+                                                                 const double *__restrict__ Yrows) {
+    extern __shared__ __attribute__((aligned(16))) double strips[];  // Ms[64][r] | Rs[64][r] (| Ys[64][r] | is[r][r])
     if (accept_dev ? accept_dev[blockIdx.z] <= 0 : !accept.v[blockIdx.z]) return;  // chain = blockIdx.z
     K += blockIdx.z * ch.k;
     out += blockIdx.z * ch.k;
@@ -450,10 +497,29 @@ __global__ __launch_bounds__(LR_THREADS) void rank_update_kernel(const double *_
     R += blockIdx.z * ch.ws;
     double *Ms = strips, *Rs = strips + 64 * r;
     const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
-    for (int e = threadIdx.x; e < 64 * r; e += LR_THREADS) {
-        const int q = e / r, a = e - q * r;
-        Ms[e] = (row0 + q < N) ? M[(size_t)(row0 + q) * r + a] : 0.0;
-        Rs[e] = (col0 + q < N) ? R[(size_t)(col0 + q) * r + a] : 0.0;
+    if (inv) {
+        inv += blockIdx.z * ch.ws;
+        Yrows += blockIdx.z * ch.ws;
+        double *Ys = strips + 2 * 64 * r, *is = strips + 3 * 64 * r;
+        for (int e = threadIdx.x; e < 64 * r; e += LR_THREADS) {
+            const int q = e / r;
+            Ys[e] = (row0 + q < N) ? Yrows[(size_t)(row0 + q) * r + (e - q * r)] : 0.0;
+        }
+        for (int e = threadIdx.x; e < r * r; e += LR_THREADS) is[e] = inv[e];
+        __syncthreads();
+        for (int e = threadIdx.x; e < 64 * r; e += LR_THREADS) {
+            const int q = e / r, c = e - q * r;
+            double s = 0.0;
+            for (int a = 0; a < r; ++a) s = fma(Ys[q * r + a], is[a * r + c], s);
+            Ms[e] = (row0 + q < N) ? s : 0.0;
+            Rs[e] = (col0 + q < N) ? R[(size_t)(col0 + q) * r + (e - q * r)] : 0.0;
+        }
+    } else {
+        for (int e = threadIdx.x; e < 64 * r; e += LR_THREADS) {
+            const int q = e / r, a = e - q * r;
+            Ms[e] = (row0 + q < N) ? M[(size_t)(row0 + q) * r + a] : 0.0;
+            Rs[e] = (col0 + q < N) ? R[(size_t)(col0 + q) * r + a] : 0.0;
+        }
     }
     __syncthreads();
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // lanes run along a row: coalesced 512 B
@@ -469,12 +535,14 @@ __global__ __launch_bounds__(LR_THREADS) void rank_update_kernel(const double *_
 }
 
 // U[i][c] = s if bit c of point i's one-hot leaf code is set else 0  (codes: [words][npad] planes)
+// flag != nullptr: also clears the chain's "singular" flag (small_kernel, later in the stream, sets it) — a memset launch less.
 __global__ __launch_bounds__(LR_THREADS) void expand_onehot_kernel(const uint32_t *__restrict__ codes, int words, int npad,
                                                                    int N, int r, ChainDoubles scales,
-                                                                   double *__restrict__ U, Chain ch) {
+                                                                   double *__restrict__ U, Chain ch, int *__restrict__ flag) {
     const double s = scales.v[blockIdx.y];  // chain = blockIdx.y; codes are (chains, words, npad) contiguous
     codes += (size_t)blockIdx.y * words * npad;
     U += blockIdx.y * ch.ws;
+    if (flag && blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<int *>(reinterpret_cast<double *>(flag) + blockIdx.y * ch.ws) = 0;
     const size_t e = (size_t)blockIdx.x * LR_THREADS + threadIdx.x;
     if (e >= (size_t)N * r) return;
     const int i = (int)(e / r), c = (int)(e - (size_t)i * r);
@@ -539,14 +607,20 @@ int launch_colsum(hipStream_t stream, const double *K, const double *U, int N, i
 }
 
 // shares -> sums -> den^-1, log|det|, dquad
+// dec != nullptr (device-side sweeps): one launch — small_kernel sums the shares itself and takes the Metropolis decision
 void launch_small(hipStream_t stream, const double *partial, int nblocks, int r, const ChainInts &r_neg, double *sums,
                   double *inv, double *logabsdet, int *flag, double *dquad, int nc = 1, Chain ch = Chain{0, 0},
-                  int out_stride = 0) {
+                  int out_stride = 0, const DecideArgs *dec = nullptr) {
     const int per = r * r + r;
+    if (dec) {
+        hipLaunchKernelGGL(small_kernel, dim3((unsigned)nc), dim3(LR_THREADS), 0, stream, sums, r, r_neg, inv, logabsdet, flag,
+                           dquad, ch, out_stride, partial, nblocks, *dec);
+        return;
+    }
     hipLaunchKernelGGL(reduce_shares_kernel, dim3((unsigned)((per + 3) / 4), (unsigned)nc), dim3(LR_THREADS), 0, stream,
                        partial, nblocks, per, sums, ch);
     hipLaunchKernelGGL(small_kernel, dim3((unsigned)nc), dim3(LR_THREADS), 0, stream, sums, r, r_neg, inv, logabsdet, flag,
-                       dquad, ch, out_stride);
+                       dquad, ch, out_stride, (const double *)nullptr, 0, DecideArgs{});
 }
 
 ChainInts one_int(int v) {
@@ -556,14 +630,21 @@ ChainInts one_int(int v) {
 }
 
 // M = Y den^-1, then out = K - M R'  for the chains whose accept entry is set
+// fused (device-side sweeps): no left_factor launch — rank_update_kernel forms its rows of M itself
 void launch_rewrite(hipStream_t stream, const double *K, int N, int r, const double *Y, const double *inv, double *M,
                     const double *R, double *out, const ChainInts &accept, int nc = 1, Chain ch = Chain{0, 0},
-                    const int32_t *accept_dev = nullptr) {
+                    const int32_t *accept_dev = nullptr, bool fused = false) {
+    const unsigned tiles = (unsigned)((N + 63) / 64);
+    if (fused) {
+        hipLaunchKernelGGL(rank_update_kernel, dim3(tiles, tiles, (unsigned)nc), dim3(LR_THREADS),
+                           (size_t)(3 * 64 * r + r * r) * sizeof(double), stream, K, M, R, N, r, out, ch, accept, accept_dev, inv, Y);
+        return;
+    }
     hipLaunchKernelGGL(left_factor_kernel, dim3((unsigned)(((size_t)N * r + LR_THREADS - 1) / LR_THREADS), (unsigned)nc),
                        dim3(LR_THREADS), 0, stream, Y, inv, N, r, M, ch, accept, accept_dev);
-    const unsigned tiles = (unsigned)((N + 63) / 64);
     hipLaunchKernelGGL(rank_update_kernel, dim3(tiles, tiles, (unsigned)nc), dim3(LR_THREADS),
-                       (size_t)2 * 64 * r * sizeof(double), stream, K, M, R, N, r, out, ch, accept, accept_dev);
+                       (size_t)2 * 64 * r * sizeof(double), stream, K, M, R, N, r, out, ch, accept, accept_dev,
+                       (const double *)nullptr, (const double *)nullptr);
 }
 
 // Metropolis decision of one tree proposal per chain on the device (bark_sampler.py:256-264):
@@ -778,7 +859,7 @@ int bark_tree_swap_eval_hip(bark_ctx *ctx, const double *K_inv, int64_t N, const
     ChainDoubles scales = {};
     scales.v[0] = s;
     hipLaunchKernelGGL(expand_onehot_kernel, dim3((unsigned)((N * r + LR_THREADS - 1) / LR_THREADS)), dim3(LR_THREADS), 0,
-                       stream, codes, words, (int)bark_leaf_npad(N), (int)N, (int)r, scales, U, Chain{0, 0});
+                       stream, codes, words, (int)bark_leaf_npad(N), (int)N, (int)r, scales, U, Chain{0, 0}, (int *)nullptr);
     BARK_LAUNCH_CHECK();
     return bark_lowrank_swap_eval_hip(K_inv, N, U, r_old, r - r_old, y, scalars_out, workspace, base, stream_);
 }
@@ -805,9 +886,11 @@ size_t bark_tree_swap_chains_workspace_bytes(int64_t N, int64_t r, int64_t nc, s
 // One proposal per chain: leaf walk of the nc [old, new] pairs, U, Y = K_inv U, the r x r algebra -> scalars_out
 // (nc, 2).  Chain b's workspace block starts `stride` bytes after chain b-1's (>= the block size for this r); the
 // codes of all chains follow at ws + stride * nc.
+// dec != nullptr (bark_tree_sweep_chains_hip, column form): the Metropolis decision is taken inside small_kernel — *decided = true
 static int eval_chains(bark_ctx *ctx, const double *K_inv, int64_t N, int64_t nc, const void *packed, const bark_pack_info *info,
                        const double *X, int64_t d, const int64_t *r_old, const double *s, const double *y,
-                       double *scalars_out, char *ws, size_t stride, hipStream_t caller) {
+                       double *scalars_out, char *ws, size_t stride, hipStream_t caller, const DecideArgs *dec = nullptr,
+                       bool *decided = nullptr) {
     const int64_t r = info->max_bits;
     if (colsum_usable(N, r)) {
         // one launch sequence for all chains: the chain index is a grid dimension of every kernel
@@ -826,14 +909,14 @@ static int eval_chains(bark_ctx *ctx, const double *K_inv, int64_t N, int64_t nc
             r_negs.v[b] = (int)r_old[b];
         }
         hipLaunchKernelGGL(expand_onehot_kernel, dim3((unsigned)((N * r + LR_THREADS - 1) / LR_THREADS), (unsigned)nc),
-                           dim3(LR_THREADS), 0, caller, codes, words, (int)bark_leaf_npad(N), (int)N, (int)r, scales, U, ch);
+                           dim3(LR_THREADS), 0, caller, codes, words, (int)bark_leaf_npad(N), (int)N, (int)r, scales, U, ch, w.flag);
         BARK_LAUNCH_CHECK();
         const int nblocks = launch_colsum(caller, K_inv, U, (int)N, (int)r, w.P, w.Y, y, w.partial, (int)nc, ch);
         BARK_LAUNCH_CHECK();
-        BARK_HIP_CHECK(hipMemset2DAsync(w.flag, stride, 0, sizeof(int), (size_t)nc, caller));
         launch_small(caller, w.partial, nblocks, (int)r, r_negs, w.sums, w.inv, scalars_out + 1, w.flag, scalars_out, (int)nc,
-                     ch, 2);
+                     ch, 2, dec);
         BARK_LAUNCH_CHECK();
+        if (decided) *decided = dec != nullptr;
         return BARK_OK;
     }
     // general shapes (odd N, more than 16 leaves): one single-chain sequence per chain, each on its own stream
@@ -926,15 +1009,22 @@ int bark_tree_sweep_chains_hip(bark_ctx *ctx, double *K_inv, int64_t N, int64_t 
     for (int64_t t = 0; t < n_steps; ++t) {
         const bark_pack_info &in = infos[t];
         const int64_t r = in.max_bits;
+        // Up to N ~ 1000 a sweep is bound by the host's launch rate (~7 us per launch, whatever N): six launches per tree proposal
+        // instead of ten — the flag memset in expand_onehot_kernel, shares + Metropolis decision in small_kernel, M = Y den^-1
+        // in rank_update_kernel (50 proposals at N = 128 .. 1000: 3.7 -> 2.3 ms).
+        int32_t *acc = accept_out + t * nc;
+        const DecideArgs dec{log_q_prior + t * nc, log_u + t * nc, state, t > 0 ? acc - nc : nullptr, acc};
+        bool decided = false;
         int rc = eval_chains(ctx, K_inv, N, nc, static_cast<const char *>(packed) + packed_offsets[t], &in, X, d, r_old + t * nc, s,
-                             y, scalars, ws, stride, caller);
+                             y, scalars, ws, stride, caller, &dec, &decided);
         if (rc) return rc;
         const LowRankWs w = lowrank_ws(ws, N, r);
-        int32_t *acc = accept_out + t * nc;
-        hipLaunchKernelGGL(decide_kernel, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, caller, scalars, log_q_prior + t * nc,
-                           log_u + t * nc, w.flag, stride / sizeof(int), (int)nc, state, t > 0 ? acc - nc : nullptr, acc);
-        BARK_LAUNCH_CHECK();
-        launch_rewrite(caller, K_inv, (int)N, (int)r, w.Y, w.inv, w.M, w.Y, K_inv, ChainInts{}, (int)nc, ch, acc);
+        if (!decided) {  // general shapes (per-chain streams): the decision as a launch of its own
+            hipLaunchKernelGGL(decide_kernel, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, caller, scalars, log_q_prior + t * nc,
+                               log_u + t * nc, w.flag, stride / sizeof(int), (int)nc, state, t > 0 ? acc - nc : nullptr, acc);
+            BARK_LAUNCH_CHECK();
+        }
+        launch_rewrite(caller, K_inv, (int)N, (int)r, w.Y, w.inv, w.M, w.Y, K_inv, ChainInts{}, (int)nc, ch, acc, decided);
         BARK_LAUNCH_CHECK();
     }
     return BARK_OK;
