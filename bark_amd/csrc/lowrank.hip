@@ -195,14 +195,28 @@ constexpr int CS_FIN_ROWS = 16;  // rows of Y per colsum_finish_kernel workgroup
 // at N = 1000 for 8 MB) — 32 rows up to N = 1024, 64 up to 2048: still at most 32 partials
 inline int colsum_segment(int64_t N) { return N <= 1024 ? 32 : N <= 2048 ? 64 : 128 * (int)((N + 4095) / 4096); }
 
-template <int RT>
+// U given as one-hot leaf codes (tree swaps in column form: r <= 16 leaf vectors = the bits of ONE code word per point, scaled
+// by the chain's s): the kernels read the word and test a bit instead of loading r doubles of a materialised U — and the
+// expand launch in front of them is gone (one dependent launch less per proposal).  Entry U[k][c] = bit c of codes[k] ? s : 0.
+struct OneHot {
+    const uint32_t *codes;  // (chains, 1, npad) or nullptr: U is a matrix
+    int npad;
+    ChainDoubles scales;
+    int *flag;  // cleared by colsum_kernel's first workgroup per chain (the "singular" flag small_kernel sets later)
+};
+
+template <int RT, bool ONEHOT>
 __global__ __launch_bounds__(LR_THREADS) void colsum_kernel(const double *__restrict__ K, const double *__restrict__ U,
                                                             int N, int r, int seg_rows, double *__restrict__ P,
-                                                            Chain ch) {
+                                                            Chain ch, OneHot oh) {
     extern __shared__ __attribute__((aligned(16))) double red[];  // [4][128][r]
     K += blockIdx.z * ch.k;  // chain = blockIdx.z
     U += blockIdx.z * ch.ws;
     P += blockIdx.z * ch.ws;
+    const uint32_t *cw = ONEHOT ? oh.codes + (size_t)blockIdx.z * oh.npad : nullptr;
+    const double sc = ONEHOT ? oh.scales.v[blockIdx.z] : 0.0;
+    if (ONEHOT && oh.flag && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        *reinterpret_cast<int *>(reinterpret_cast<double *>(oh.flag) + blockIdx.z * ch.ws) = 0;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = blockIdx.x * 128 + 2 * lane;
@@ -221,10 +235,11 @@ __global__ __launch_bounds__(LR_THREADS) void colsum_kernel(const double *__rest
 #pragma unroll
         for (int u = 0; u < CS_UNROLL; ++u) {
             const double *urow = U + (size_t)min(k0 + u, N - 1) * r;  // wave-uniform address: scalar loads
+            const uint32_t word = ONEHOT ? cw[min(k0 + u, N - 1)] : 0u;
 #pragma unroll
             for (int c = 0; c < RT; ++c)
                 if (c < r) {
-                    const double uv = urow[c];
+                    const double uv = ONEHOT ? (((word >> c) & 1u) ? sc : 0.0) : urow[c];
                     ax[c] = fma(kv[u].x, uv, ax[c]);
                     ay[c] = fma(kv[u].y, uv, ay[c]);
                 }
@@ -249,7 +264,7 @@ __global__ __launch_bounds__(LR_THREADS) void colsum_kernel(const double *__rest
 __global__ __launch_bounds__(LR_THREADS) void colsum_finish_kernel(const double *__restrict__ P, int segs,
                                                                    const double *__restrict__ U, int N, int r,
                                                                    double *__restrict__ Y, const double *__restrict__ y,
-                                                                   double *__restrict__ partial, Chain ch) {
+                                                                   double *__restrict__ partial, Chain ch, OneHot oh) {
     extern __shared__ __attribute__((aligned(16))) double sh[];  // ys[ROWS][r] | ur[ROWS][r] | yv[ROWS]
     constexpr int ROWS = CS_FIN_ROWS;
     P += blockIdx.y * ch.ws;  // chain = blockIdx.y; y is shared by the chains
@@ -266,7 +281,14 @@ __global__ __launch_bounds__(LR_THREADS) void colsum_finish_kernel(const double 
 #pragma unroll 8
             for (int sg = 0; sg < segs; ++sg) v += P[(size_t)sg * N * r + at];
             Y[at] = v;
-            if (partial) uv = U[at];
+            if (partial) {
+                if (oh.codes) {
+                    const int q = e / r, c = e - q * r;
+                    uv = ((oh.codes[(size_t)blockIdx.y * oh.npad + row0 + q] >> c) & 1u) ? oh.scales.v[blockIdx.y] : 0.0;
+                } else {
+                    uv = U[at];
+                }
+            }
         }
         ys[e] = v;
         ur[e] = uv;
@@ -592,17 +614,22 @@ int launch_skinny(hipStream_t stream, const double *K, const double *U, int N, i
 bool colsum_usable(int64_t N, int64_t r) { return N % 2 == 0 && r <= 16; }
 
 int launch_colsum(hipStream_t stream, const double *K, const double *U, int N, int r, double *P, double *out,
-                  const double *y, double *partial, int nc = 1, Chain ch = Chain{0, 0}) {
+                  const double *y, double *partial, int nc = 1, Chain ch = Chain{0, 0}, const OneHot *onehot = nullptr) {
     const int seg_rows = colsum_segment(N), segs = (N + seg_rows - 1) / seg_rows;
     const dim3 grid((unsigned)((N + 127) / 128), (unsigned)segs, (unsigned)nc);
     const size_t lds = (size_t)4 * 128 * r * sizeof(double);  // 64 KiB at r = 16
-    if (r <= 8)
-        hipLaunchKernelGGL((colsum_kernel<8>), grid, dim3(LR_THREADS), lds, stream, K, U, N, r, seg_rows, P, ch);
+    const OneHot oh = onehot ? *onehot : OneHot{nullptr, 0, ChainDoubles{}, nullptr};
+    if (onehot && r <= 8)
+        hipLaunchKernelGGL((colsum_kernel<8, true>), grid, dim3(LR_THREADS), lds, stream, K, U, N, r, seg_rows, P, ch, oh);
+    else if (onehot)
+        hipLaunchKernelGGL((colsum_kernel<16, true>), grid, dim3(LR_THREADS), lds, stream, K, U, N, r, seg_rows, P, ch, oh);
+    else if (r <= 8)
+        hipLaunchKernelGGL((colsum_kernel<8, false>), grid, dim3(LR_THREADS), lds, stream, K, U, N, r, seg_rows, P, ch, oh);
     else
-        hipLaunchKernelGGL((colsum_kernel<16>), grid, dim3(LR_THREADS), lds, stream, K, U, N, r, seg_rows, P, ch);
+        hipLaunchKernelGGL((colsum_kernel<16, false>), grid, dim3(LR_THREADS), lds, stream, K, U, N, r, seg_rows, P, ch, oh);
     const int nblocks = (N + CS_FIN_ROWS - 1) / CS_FIN_ROWS;
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)nblocks, (unsigned)nc), dim3(LR_THREADS),
-                       (size_t)(2 * CS_FIN_ROWS * r + CS_FIN_ROWS) * sizeof(double), stream, P, segs, U, N, r, out, y, partial, ch);
+                       (size_t)(2 * CS_FIN_ROWS * r + CS_FIN_ROWS) * sizeof(double), stream, P, segs, U, N, r, out, y, partial, ch, oh);
     return nblocks;
 }
 
@@ -908,10 +935,9 @@ static int eval_chains(bark_ctx *ctx, const double *K_inv, int64_t N, int64_t nc
             scales.v[b] = s[b];
             r_negs.v[b] = (int)r_old[b];
         }
-        hipLaunchKernelGGL(expand_onehot_kernel, dim3((unsigned)((N * r + LR_THREADS - 1) / LR_THREADS), (unsigned)nc),
-                           dim3(LR_THREADS), 0, caller, codes, words, (int)bark_leaf_npad(N), (int)N, (int)r, scales, U, ch, w.flag);
-        BARK_LAUNCH_CHECK();
-        const int nblocks = launch_colsum(caller, K_inv, U, (int)N, (int)r, w.P, w.Y, y, w.partial, (int)nc, ch);
+        // r <= 16 here (colsum_usable): the one-hot U is one code word per point — read by the kernels, never materialised
+        const OneHot oh{codes, (int)bark_leaf_npad(N), scales, w.flag};
+        const int nblocks = launch_colsum(caller, K_inv, U, (int)N, (int)r, w.P, w.Y, y, w.partial, (int)nc, ch, &oh);
         BARK_LAUNCH_CHECK();
         launch_small(caller, w.partial, nblocks, (int)r, r_negs, w.sums, w.inv, scalars_out + 1, w.flag, scalars_out, (int)nc,
                      ch, 2, dec);
