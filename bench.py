@@ -721,6 +721,43 @@ def sampler_step_probe(args, wl):
                                            "(numpy, N x N copies as the reference makes)" % n_cpu}
         del cb
         torch.cuda.empty_cache()
+    # the regime BARK itself samples in (tens to hundreds of points, one chain): a proposal is a chain of five small dependent
+    # launches there, not bytes — the tree sweep alone, beside the oracle's chain on the same proposals
+    small = {}
+    for Ns in (128, 512):
+        Xs, ys, bounds_s, fts = synthetic.unit_cube_problem(Ns, wl.d, seed=Ns)
+        cur = synthetic.sample_prior_forests(1, m, bounds_s, fts, seed=7000)
+        prop = synthetic.sample_prior_forests(1, m, bounds_s, fts, seed=8000)
+        noise, scale = np.full(1, 0.1), np.ones(1)
+        log_q, log_u = rng.normal(0.0, 0.5, size=(1, m)), np.log(rng.uniform(size=(1, m)))
+        Xsd = torch.from_numpy(Xs).to(Xd.device)
+        walls = []
+        for it in range(4):
+            cb = fit.ChainBatch.from_forests(cur, noise, scale, Xsd, ys, fts)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            cb.sweep_trees(cur, prop, log_q, log_u, Xsd, fts, scale, m)
+            torch.cuda.synchronize()
+            walls.append(time.perf_counter() - t0)
+        row = {"tree_sweep_wall_ms": 1e3 * sorted(walls[1:])[1], "ms_per_tree_proposal": 1e3 * sorted(walls[1:])[1] / m}
+        if args.cpu_sample > 0:
+            from oracle import oracle as orc
+
+            K = orc.forest_gram_matrix(cur[0], Xs, Xs, fts)
+            K[np.diag_indices(Ns)] += 1e-6 + 0.1
+            K_inv, logdet = np.linalg.inv(K), np.linalg.slogdet(K)[1]
+            t = time.perf_counter()
+            for ti in range(10):
+                U_old = np.sqrt(1.0 / m) * orc.get_leaf_vectors(cur[0, ti], Xs, fts)
+                U_new = np.sqrt(1.0 / m) * orc.get_leaf_vectors(prop[0, ti], Xs, fts)
+                K1 = orc.low_rank_inv_update(K_inv, U_old, subtract=True)
+                d1 = orc.low_rank_det_update(K_inv, U_old, logdet, subtract=True)
+                K2 = orc.low_rank_inv_update(K1, U_new)
+                orc.mll(K2, orc.low_rank_det_update(K1, U_new, d1), ys)
+            row["cpu_oracle_ms_per_tree_proposal"] = 1e3 * (time.perf_counter() - t) / 10
+        small["N=%d" % Ns] = row
+        del cb
+    out["small_n_one_chain"] = small
     return out
 
 
