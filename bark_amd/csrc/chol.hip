@@ -1202,8 +1202,95 @@ __device__ __forceinline__ void y_commit(const double *part, double *yi, int tid
 // ---------------------------------------------------------------------------------------------
 // kdone: block rows of the K range this launch covers (j in the plain schedule; j - 1 in the pipelined one, where
 // solve_kernel<1> / diag_kernel apply the rest).
+// The partial DIAGONAL tile P[j+1,j+1] = A - sum_k U[k,j+1]'U[k,j+1] is symmetric and only its upper block triangle is ever
+// read (diag_kernel / diag_pre_kernel take the 36 sub-blocks rb <= cb), so it is a SYRK, not a GEMM: 36 of the 64 16 x 16
+// sub-block products, nine per wave (UpperBlocks, as diag_update), both MFMA operands from ONE LDS-DMA stage of the one panel
+// (half the DMA of a square tile).  The diagonal tile is one of 32 - j tiles of a block row with the longest K each: 9.1 % of
+// the row launches' tile x block-row products at N = 4096, of which this saves 7 / 16.  Per element the MFMA sequence is that
+// of the square tile (k ascending, four k per MFMA): identical bits in the upper block triangle; the sub-blocks below it are
+// not written.
+template <int GEN, int W>
+__device__ __forceinline__ void syrk_tile(const Mats &p, int b, int cbk, const double *__restrict__ panel, int K, double *tile,
+                                          double *lds, int tid, int lane, int lr, int lk) {
+    using T = UpperBlocks<W>;
+    f64x4 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    // k-tiles of 32 rows (one operand: two of them fill the 72 KiB the square tile's two 16-row A + B stages take): 72 MFMAs per
+    // wave between barriers.  With 16-row k-tiles (36 MFMAs, ~1 us) the next stage's DMA round trip, not the products, set the
+    // pace: the tile took as long as a square one.
+    constexpr int SK = 2 * BK;
+    const int nk = K / SK;
+    auto stage = [&](int kt, double *st) {  // wave W moves rows W, W+4, ..., W+28 of the k-tile
+#pragma unroll
+        for (int pp = 0; pp < SK / 4; ++pp) dma_row(panel + (size_t)(kt * SK + W + 4 * pp) * p.ld + lane * 2, st + (W + 4 * pp) * LDS_LD);
+    };
+    if (nk > 0) {
+        stage(0, lds);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) stage(kt + 1, lds + ((kt + 1) & 1) * (SK * LDS_LD));
+            const double *st = lds + (kt & 1) * (SK * LDS_LD);
+#pragma unroll
+            for (int kk = 0; kk < SK / 4; ++kk) {
+                double fr[8];
+#pragma unroll
+                for (int blk = 0; blk < 8; ++blk)
+                    if (blk >= W) fr[blk] = st[(kk * 4 + lk) * LDS_LD + blk * 16 + lr];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[T::rb[i]], fr[T::cb[i]], acc[i], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    if (GEN == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                double *e = tile + (size_t)(T::rb[i] * 16 + lk + 4 * v) * p.ld + T::cb[i] * 16 + lr;
+                *e = *e - acc[i][v];
+            }
+        return;
+    }
+    // A generated from the leaf codes, form_tile's arithmetic operation for operation (rows and columns are the same points)
+    const int npad = p.nrb * NB;
+    uint32_t *codes = reinterpret_cast<uint32_t *>(lds);  // [nW][128]
+    const uint32_t *lb = p.leafx + (size_t)b * p.nW * npad;
+    for (int e = tid; e < p.nW * NB; e += THREADS) codes[e] = lb[(size_t)(e >> 7) * npad + cbk * NB + (e & (NB - 1))];
+    __syncthreads();
+    const double inv_m = 1.0 / (double)p.m;
+    const bool has_scale = p.scale != nullptr, has_shift = p.shift != nullptr;
+    const double sc = has_scale ? p.scale[b] : 1.0, sh = has_shift ? p.shift[b] : 0.0, jitter = 1e-6 + p.noise[b];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        uint32_t cnt[4] = {0, 0, 0, 0};
+        for (int w = 0; w < p.nW; ++w) {
+            const uint32_t cw = codes[w * NB + T::cb[i] * 16 + lr];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) cnt[v] += code_count<(GEN > 0 ? GEN - 1 : 0)>(codes[w * NB + T::rb[i] * 16 + lk + 4 * v], cw);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = T::rb[i] * 16 + lk + 4 * v, cc = T::cb[i] * 16 + lr, gi = cbk * NB + r, gj = cbk * NB + cc;
+            double val;
+            if (gi < p.N && gj < p.N) {
+                val = inv_m * (double)agree_count<(GEN > 0 ? GEN - 1 : 0)>(cnt[v], p.m);
+                if (has_shift) val = val - sh;
+                if (has_scale) val = sc * val;
+                if (gi == gj) val = val + jitter;
+            } else {
+                val = gi == gj ? 1.0 : 0.0;  // identity padding
+            }
+            tile[(size_t)r * p.ld + cc] = val - acc[i][v];
+        }
+    }
+}
+
 template <int GEN>  // 0: A tile read from HBM; 1 + LeafRep: A generated from the leaf codes (bytes8 / bytes7 / bits)
-__global__ __launch_bounds__(THREADS, 2) void row_kernel(Mats p, int j, int kdone, int n_right, int n_tiles) {
+__global__ __launch_bounds__(THREADS, 2) void row_kernel(Mats p, int j, int kdone, int n_right, int n_tiles, int syrk) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
     int b, t;
@@ -1212,6 +1299,19 @@ __global__ __launch_bounds__(THREADS, 2) void row_kernel(Mats p, int j, int kdon
     double *Ab = p.A + (size_t)b * p.bstride;
     const int rb = t < n_right ? j : j + 1;
     const int cb = t < n_right ? j + 1 + t : j + 1;
+    if (syrk && rb == cb) {  // workgroup-uniform: the partial diagonal tile
+        const int wsel = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        double *tile = Ab + (size_t)rb * NB * p.ld + (size_t)cb * NB;
+        if (wsel == 0)
+            syrk_tile<GEN, 0>(p, b, cb, Ab + (size_t)cb * NB, kdone * NB, tile, lds, tid, lane, q.lr, q.lk);
+        else if (wsel == 1)
+            syrk_tile<GEN, 1>(p, b, cb, Ab + (size_t)cb * NB, kdone * NB, tile, lds, tid, lane, q.lr, q.lk);
+        else if (wsel == 2)
+            syrk_tile<GEN, 2>(p, b, cb, Ab + (size_t)cb * NB, kdone * NB, tile, lds, tid, lane, q.lr, q.lk);
+        else
+            syrk_tile<GEN, 3>(p, b, cb, Ab + (size_t)cb * NB, kdone * NB, tile, lds, tid, lane, q.lr, q.lk);
+        return;
+    }
     f64x4 acc[4][4];
     zero_acc(acc);
     gemm_kmajor_dma(acc, Ab + (size_t)rb * NB, p.ld, Ab + (size_t)cb * NB, p.ld, kdone * NB, lds, tid, q);
@@ -1746,7 +1846,14 @@ constexpr int PIPE_MIN_NRB = BARK_PIPE_MIN_NRB;  // fewer block rows: plain sche
 #ifndef BARK_PLAIN_CHUNK_MULTIPLE
 #define BARK_PLAIN_CHUNK_MULTIPLE 256
 #endif
-constexpr int PLAIN_CHUNK_MULTIPLE = BARK_PLAIN_CHUNK_MULTIPLE;  // chunks of a multiple of this many matrices (and > 16 block rows): plain
+constexpr int PLAIN_CHUNK_MULTIPLE = BARK_PLAIN_CHUNK_MULTIPLE;  // chunks of a multiple of this many matrices (and >= PLAIN_MIN_NRB block rows): plain
+// round 4, with the diagonal tile as a SYRK in the pipelined launches — plain | pipelined, ms, same box: N = 2200 x 256 19.31 | 18.63,
+// N = 3000 x 256 42.84 | 41.95, N = 4096 x 256 96.2 / 96.7 | 95.8 / 97.1 (a tie, as before), N = 4096 x 512 192.5 | 193.4,
+// N = 8192 x 256 726.8 | 743.3: the rule used to be 16 block rows
+#ifndef BARK_PLAIN_MIN_NRB
+#define BARK_PLAIN_MIN_NRB 32
+#endif
+constexpr int PLAIN_MIN_NRB = BARK_PLAIN_MIN_NRB;
 #ifndef BARK_SOLVE_NARROW_MAX_WGS
 #define BARK_SOLVE_NARROW_MAX_WGS 256
 #endif
@@ -1909,18 +2016,24 @@ struct Sweep {
         return BARK_OK;
     }
 
-    int launch_rows(hipStream_t st, int j, int kdone, int n_right, int n_tiles) {
+    // syrk: the partial diagonal tile as a SYRK (syrk_tile) — 7/16 less work in one workgroup of every matrix.  Pays where row
+    // launches overlap (pipelined schedule: N = 4096 x 192 71.8 -> 70.5 ms, N = 2200 x 256 19.1 -> 18.6, B = 256 95.8 -> 94.1);
+    // in the plain schedule of a chunk that is a multiple of the CU count every workgroup of a launch has the same length and
+    // the launch advances in lock step — the co-running tiles of a matrix stream the shared A panel through L2 at the same k —
+    // and one shorter workgroup per matrix breaks that: N = 4096 x 256 94.5 -> 97.4 ms (profiles/r04/headline_power_wall.txt)
+    int launch_rows(hipStream_t st, int j, int kdone, int n_right, int n_tiles, int syrk) {
         const dim3 g(xcd_grid(n_tiles, p.Bc)), blk(THREADS);
         if (!fused)
-            hipLaunchKernelGGL(row_kernel<0>, g, blk, GEMM_LDS, st, p, j, kdone, n_right, n_tiles);
+            hipLaunchKernelGGL(row_kernel<0>, g, blk, GEMM_LDS, st, p, j, kdone, n_right, n_tiles, syrk);
         else if (rep == REP_BITS)
-            hipLaunchKernelGGL(row_kernel<1 + REP_BITS>, g, blk, GEMM_LDS, st, p, j, kdone, n_right, n_tiles);
+            hipLaunchKernelGGL(row_kernel<1 + REP_BITS>, g, blk, GEMM_LDS, st, p, j, kdone, n_right, n_tiles, syrk);
         else if (rep == REP_BYTES7)
-            hipLaunchKernelGGL(row_kernel<1 + REP_BYTES7>, g, blk, GEMM_LDS, st, p, j, kdone, n_right, n_tiles);
+            hipLaunchKernelGGL(row_kernel<1 + REP_BYTES7>, g, blk, GEMM_LDS, st, p, j, kdone, n_right, n_tiles, syrk);
         else
-            hipLaunchKernelGGL(row_kernel<1 + REP_BYTES8>, g, blk, GEMM_LDS, st, p, j, kdone, n_right, n_tiles);
+            hipLaunchKernelGGL(row_kernel<1 + REP_BYTES8>, g, blk, GEMM_LDS, st, p, j, kdone, n_right, n_tiles, syrk);
         BARK_LAUNCH_CHECK();
-        panel_flops += 2.0 * NB * NB * (double)(kdone * NB) * (double)n_tiles * (double)p.Bc;
+        // executed flops: with syrk the partial diagonal tile (present when n_tiles > n_right) takes 36 of 64 sub-block products
+        panel_flops += 2.0 * NB * NB * (double)(kdone * NB) * ((double)n_right + (n_tiles > n_right ? (syrk ? 36.0 / 64.0 : 1.0) : 0.0)) * (double)p.Bc;
         return BARK_OK;
     }
 
@@ -2138,7 +2251,7 @@ struct Sweep {
                 int tail, St;
                 ragged_tail(j, n_tiles, tail, St);
                 if (tail > 0) {
-                    if ((r = launch_rows(ps, j, j, n_right, tail))) return r;
+                    if ((r = launch_rows(ps, j, j, n_right, tail, 0))) return r;
                 }
                 if (tail < n_tiles) {
                     if ((r = launch_split(ps, j, 0, j, St, 0, St, tail, n_tiles - tail))) return r;
@@ -2211,7 +2324,7 @@ struct Sweep {
         if (S >= 2) {
             if ((r = launch_split(st, j, 0, k, S, 0, S))) return r;
             if ((r = launch_reduce(st, j, S))) return r;
-        } else if ((r = launch_rows(st, j, k, ncb - j - 1, nt))) {
+        } else if ((r = launch_rows(st, j, k, ncb - j - 1, nt, 1))) {
             return r;
         }
         if ((r = mark_on(st))) return r;
@@ -2496,7 +2609,7 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
     if ((rc = sw.mark_on(caller))) return rc;
     for (int64_t c0 = 0; c0 < B; c0 += Bc) {  // chunks of Bc resident matrices, one after the other
         const int64_t bc = (B - c0 < Bc) ? (B - c0) : Bc;
-        sw.pipelined = pipeline_ok && ((bc % PLAIN_CHUNK_MULTIPLE) != 0 || nrb <= 16);
+        sw.pipelined = pipeline_ok && ((bc % PLAIN_CHUNK_MULTIPLE) != 0 || nrb < PLAIN_MIN_NRB);
         if (nrb == 1 && fused && C == 0 && !timing) {  // N <= 128: leaf walk + ONE launch per chunk (OneBlock)
             Mats &p1 = sw.p;
             bark_pack_info sub = *info;
@@ -2672,7 +2785,7 @@ static int leafspace_run(bark_ctx *ctx, const void *packed, const bark_pack_info
         const char *packed_c = static_cast<const char *>(packed) + (size_t)c0 * m * info->stride * 16;
         p.info = info_out + c0;
         p.Bc = (int)bc;
-        sw.pipelined = !g.L.splitk && nrb >= PIPE_MIN_NRB && ((bc % PLAIN_CHUNK_MULTIPLE) != 0 || nrb <= 16);  // as the dense entry
+        sw.pipelined = !g.L.splitk && nrb >= PIPE_MIN_NRB && ((bc % PLAIN_CHUNK_MULTIPLE) != 0 || nrb < PLAIN_MIN_NRB);  // as the dense entry
         if ((rc = walk_one_hot(packed_c, &sub, X, N, d, (int)g.W, codes, ctx->fault, caller))) return rc;
         rc = leafspace_prepare(codes, (int)g.W, (int)g.npad, planes, (int)g.R, (int)g.Rpad, noise + c0,
                                use_scale ? scale + c0 : nullptr, (int)m, (int)bc, p.A, p.ld, p.bstride, y, (int)N, p.yz,

@@ -50,8 +50,8 @@ def test_c3_b256_plain_schedule():
     """configs[2], the headline shape exactly: N = 4096, d = 8, m = 50, B = 256 forests seeded 4096 + b, noise
     U[0.05, 0.15) (examples/mcmc/mcmc_record_mll.py:57-74 convention).  256 resident matrices of 32 block
     rows is the one shape class that takes Sweep's PLAIN schedule with ragged-round splitting off (bc % 256 == 0 and
-    nrb > 16).  First / middle / last sample against the oracle's LU route, bit-reproducibility of the call, and
-    agreement with the pipelined schedule (chunk = 64)."""
+    nrb >= 32).  First / middle / last sample against the oracle's LU route, bit-reproducibility of the call, and
+    agreement with the pipelined schedule (chunk = 64: row launches with the diagonal tile as a SYRK)."""
     import torch
 
     import bark_amd.fitting as fit
@@ -75,9 +75,9 @@ def test_c3_b256_plain_schedule():
     assert np.isfinite(got).all()
 
 
-def test_plain_schedule_n2200_b256():
-    """A second shape of the plain schedule's class (18 block rows > 16, 256 resident matrices), ragged N, mixed
-    feature types, scale included."""
+def test_n2200_b256_one_chunk_of_256():
+    """256 resident matrices of 18 block rows, ragged N, mixed feature types, scale included: the plain schedule until
+    round 3, since round 4 (fewer than 32 block rows) the pipelined one with SYRK diagonal tiles in chunks of every size."""
     import bark_amd.fitting as fit
     from bark_amd import synthetic as syn
     from oracle import oracle as orc
@@ -92,6 +92,27 @@ def test_plain_schedule_n2200_b256():
     assert np.array_equal(got, fit.batched_mll(F, noise, scale, X, y, ft, chunk=256, **kw))
     assert np.allclose(got, fit.batched_mll(F, noise, scale, X, y, ft, chunk=96, **kw), rtol=1e-12, atol=0.0)
     pick = [0, 1, 127, 128, 255]
+    want = orc.batched_mll(F[pick], noise[pick], scale[pick], X, y, ft, **kw)
+    assert np.allclose(got[pick], want, rtol=MLL_RTOL, atol=MLL_ATOL), (got[pick], want)
+
+
+def test_plain_schedule_n4200_b256():
+    """A second shape of the plain schedule's class (33 block rows, 256 resident matrices), ragged N (4200 = 32 x 128 + 104:
+    identity padding in the last block row), mixed feature types, scale included."""
+    import bark_amd.fitting as fit
+    from bark_amd import synthetic as syn
+    from oracle import oracle as orc
+
+    N, B, m = 4200, 256, 50
+    X, y, bounds, ft = syn.mixed_problem(N, seed=4200)
+    F = syn.sample_prior_forests(B, m, bounds, ft, seed=4201)
+    rng = np.random.default_rng(4202)
+    noise, scale = rng.uniform(0.05, 0.3, B), rng.uniform(0.6, 1.5, B)
+    kw = dict(include_scale=True, include_2pi=False)
+    got = fit.batched_mll(F, noise, scale, X, y, ft, chunk=256, **kw)
+    assert np.array_equal(got, fit.batched_mll(F, noise, scale, X, y, ft, chunk=256, **kw))
+    assert np.allclose(got, fit.batched_mll(F, noise, scale, X, y, ft, chunk=96, **kw), rtol=1e-12, atol=0.0)
+    pick = [0, 255]
     want = orc.batched_mll(F[pick], noise[pick], scale[pick], X, y, ft, **kw)
     assert np.allclose(got[pick], want, rtol=MLL_RTOL, atol=MLL_ATOL), (got[pick], want)
 
