@@ -48,6 +48,14 @@ SIGNATURES = {
     "bark_last_error": (ctypes.c_char_p, []),
     "bark_device_wait": (ci, [ci]),
     "bark_xcd_map_selftest": (ci, [ci, ci]),
+    "bark_debug_fail_launch": (ctypes.c_long, [ctypes.c_long]),
+    "bark_dev_alloc": (ci, [vp, ctypes.c_size_t, ctypes.POINTER(vp)]),
+    "bark_dev_free": (ci, [vp, vp]),
+    "bark_ctx_upload": (ci, [vp, vp, vp, ctypes.c_size_t, vp]),
+    "bark_ctx_download": (ci, [vp, vp, vp, ctypes.c_size_t, vp]),
+    "bark_stream_sync": (ci, [vp, vp]),
+    "bark_tree_swap_eval_host_pair": (ci, [vp, vp, i64, vp, i64, vp, i64, vp, ctypes.c_double, vp, vp, vp, vp,
+                                           ctypes.c_size_t, vp]),
     "bark_comm_unique_id": (ci, [vp]),
     "bark_comm_create": (ci, [vp, ci, ci, ci, ctypes.POINTER(vp)]),
     "bark_comm_destroy": (None, [vp]),

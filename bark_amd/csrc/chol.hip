@@ -780,8 +780,12 @@ __device__ __forceinline__ void c_group(double *S, int kb, int n, int i0, int lr
 // p.sync[wait_slot] has reached wait_value — the row launch whose tiles the NEXT kernel of this stream (solve(j)) reads
 // has retired.  This replaces an event wait between diag(j) and solve(j) on the caller's stream: an unresolved
 // cross-stream event wait costs ~5-13 us there, kernels back to back 0.8 us (tools/gap_probe.hip), and the row launch
-// is normally long done.  Only this kernel spins — at most 32 workgroups, on CUs the row kernels do not need — and what
-// it waits for never waits for it (the row launch was released by an event recorded before this kernel was enqueued).
+// is normally long done.  Only this kernel spins — at most 32 workgroups, on CUs the row kernels do not need.  What keeps the
+// scheme live: workgroup 0 publishes the block step in sync[3] when it STARTS (or diag_pre_kernel does, in front of it), the
+// helper streams' gates wait for nothing else, the host enqueues the row launches behind those gates promptly, and the helper
+// streams run beside this one; where they cannot (serialised dispatch, one hardware queue) the wait is BOUNDED — 2 s, sticky
+// for the rest of the chunk, info = -3 — it is not a deadlock-freedom argument by enqueue order: the gate of a helper stream
+// is enqueued before the diag_kernel it waits for, and the rows a diag_kernel waits for are enqueued after it.
 // ONE: the one-launch evaluation of matrices of one block row (OneBlock; j == 0, nkb == 0) — an instantiation of its
 // own, so that the regular kernel carries none of its code (with a run-time switch diag_kernel ran 52 -> 60 us).
 template <bool ONE>
@@ -1014,7 +1018,14 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
             const int32_t *flag = p.sync + wait_slot;
             bool ok = true;
+            // a time-out is sticky (sync[2] != 0): once one wait of the chunk has run into its bound every later one gives up
+            // at once — under serialised dispatch (rocprofv3 --pmc, AMD_SERIALIZE_KERNEL) every wait would time out, and 2 s
+            // per block step is minutes at N = 16384; now the whole call costs one bound
             while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < wait_value) {
+                if (__hip_atomic_load(p.sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                    ok = false;
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(8);
                 if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {  // 2 s: the row stream is not running beside us
                     ok = false;
@@ -1080,10 +1091,12 @@ __global__ void sync_publish_kernel(int32_t *sync, int slot, int value) {
 
 // Gate of a helper stream: one lane waits (bounded: ~2 s, then sync[2]++ and on it goes — the call ends with info = -3)
 // until the caller's stream has reached block step `value` (diag_kernel publishes it when it starts); the row kernels
-// behind the gate in stream order start once it retires.  The kernel they depend on was enqueued before this one.
+// behind the gate in stream order start once it retires.  The diag_kernel it waits for is enqueued AFTER this gate (the host
+// runs ahead): progress relies on the caller's stream running beside this one, the bound covers the case that it cannot.
 __global__ void sync_gate_kernel(int32_t *sync, int slot, int value) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
     while (__hip_atomic_load(sync + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value) {
+        if (__hip_atomic_load(sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;  // sticky: see diag_kernel
         __builtin_amdgcn_s_sleep(4);
         if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
             atomicAdd(sync + 2, 1);
@@ -2007,12 +2020,45 @@ struct Sweep {
     std::vector<size_t> gram_marks, diag_marks, panel_marks, solve_marks;
     double panel_flops = 0.0, solve_flops = 0.0;
 
+    // Helper streams this call has put work on (bit i: res->helper / helper2 / helper3).  Whatever way the call ends, every
+    // one of them is joined back into the caller's stream (rejoin_helpers): under stream capture a forked stream that is not
+    // rejoined leaves the capture unjoined (hipStreamEndCapture then fails — or, on this ROCm, crashes: profiles/r04/
+    // capture_unjoined_probe.txt), and outside capture the caller's stream must not run ahead of — or the caller free the
+    // workspace under — kernels still queued on a helper.
+    unsigned touched = 0;
+    void touch(hipStream_t st) {
+        if (!res || st == main) return;
+        if (st == res->helper) touched |= 1u;
+        if (st == res->helper2) touched |= 2u;
+        if (st == res->helper3) touched |= 4u;
+    }
+    int after(hipStream_t st, hipEvent_t e) {  // st proceeds once e has completed
+        touch(st);
+        BARK_HIP_CHECK(hipStreamWaitEvent(st, e, 0));
+        return BARK_OK;
+    }
+    // everything enqueued on the touched helper streams so far precedes what follows on the caller's stream.  Best effort,
+    // keeps the thread's error message: it also runs on the way out of a failed call.
+    void rejoin_helpers() {
+        if (!res) return;
+        hipStream_t hs[3] = {res->helper, res->helper2, res->helper3};
+        for (int i = 0; i < 3; ++i)
+            if ((touched >> i & 1u) && hs[i] && res->rejoin[i]) {
+                if (hipEventRecord(res->rejoin[i], hs[i]) == hipSuccess) (void)hipStreamWaitEvent(main, res->rejoin[i], 0);
+            }
+        touched = 0;
+        (void)hipGetLastError();
+    }
+    ~Sweep() {
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);  // timing events of a call that did not reach report()
+    }
+
     int mark_on(hipStream_t s) {
         if (!timed) return BARK_OK;
         hipEvent_t e;
         BARK_HIP_CHECK(hipEventCreate(&e));
-        BARK_HIP_CHECK(hipEventRecord(e, s));
         ev.push_back(e);
+        BARK_HIP_CHECK(hipEventRecord(e, s));
         return BARK_OK;
     }
 
@@ -2038,12 +2084,14 @@ struct Sweep {
     }
 
     int publish(hipStream_t st, int slot, int value) {
+        touch(st);
         hipLaunchKernelGGL(sync_publish_kernel, dim3(1), dim3(1), 0, st, p.sync, slot, value);
         BARK_LAUNCH_CHECK();
         return BARK_OK;
     }
 
     int gate(hipStream_t st, int value) {  // st proceeds once the caller's stream has started diag(value - 1)
+        touch(st);
         hipLaunchKernelGGL(sync_gate_kernel, dim3(1), dim3(1), 0, st, p.sync, 3, value);
         BARK_LAUNCH_CHECK();
         return BARK_OK;
@@ -2091,8 +2139,7 @@ struct Sweep {
     int fork(int slot) {
         if (panel == main) return BARK_OK;
         BARK_HIP_CHECK(hipEventRecord(res->events[slot], main));
-        BARK_HIP_CHECK(hipStreamWaitEvent(panel, res->events[slot], 0));
-        return BARK_OK;
+        return after(panel, res->events[slot]);
     }
     // everything enqueued on the panel stream so far precedes what follows on `main`
     int join(int slot) {
@@ -2208,16 +2255,14 @@ struct Sweep {
         const bool rows_off_stream = has_rows && ps != s;
         if (dev_gate && j == 0) {  // the helper streams' gates must not read sync before the prologue has zeroed it
             BARK_HIP_CHECK(hipEventRecord(res->events[5], s));
-            BARK_HIP_CHECK(hipStreamWaitEvent(ps, res->events[5], 0));
-            BARK_HIP_CHECK(hipStreamWaitEvent(la_stream, res->events[5], 0));
-            BARK_HIP_CHECK(hipStreamWaitEvent(la_stream2, res->events[5], 0));
+            if ((r = after(ps, res->events[5])) || (r = after(la_stream, res->events[5])) || (r = after(la_stream2, res->events[5]))) return r;
         }
         if (!dev_gate && (rows_off_stream || bulk_next)) BARK_HIP_CHECK(hipEventRecord(res->events[6 * j], s));
         if (rows_off_stream) {
             if (dev_gate) {
                 if ((r = gate(ps, j + 1))) return r;
             } else {
-                BARK_HIP_CHECK(hipStreamWaitEvent(ps, res->events[6 * j], 0));
+                if ((r = after(ps, res->events[6 * j]))) return r;
             }
         }
         if (bulk_next) {
@@ -2230,7 +2275,7 @@ struct Sweep {
             if (dev_gate) {
                 if ((r = gate(ls, j + 1))) return r;
             } else {
-                BARK_HIP_CHECK(hipStreamWaitEvent(ls, res->events[6 * j], 0));
+                if ((r = after(ls, res->events[6 * j]))) return r;
             }
             if ((r = launch_split(ls, j2, 0, j2 - 1, S2, 0, S2 + 1))) return r;
             BARK_HIP_CHECK(hipEventRecord(res->events[6 * j2 + 2], ls));
@@ -2242,7 +2287,7 @@ struct Sweep {
             if ((r = mark_on(ps))) return r;
             if (la) {  // the last block row of the K range; the bulk [0, j-1) was launched after solve(j-2)
                 if ((r = launch_split(ps, j, j - 1, j, 1, S, S + 1))) return r;
-                BARK_HIP_CHECK(hipStreamWaitEvent(ps, res->events[6 * j + 2], 0));  // the bulk slabs of step j
+                if ((r = after(ps, res->events[6 * j + 2]))) return r;  // the bulk slabs of step j
                 if ((r = launch_reduce(ps, j, S + 1))) return r;
             } else if (S > 1) {
                 if ((r = launch_split(ps, j, 0, j, S, 0, S))) return r;
@@ -2306,7 +2351,7 @@ struct Sweep {
             if ((r = gate(st, j))) return r;
         } else {
             BARK_HIP_CHECK(hipEventRecord(res->events[6 * j + 3], main));
-            BARK_HIP_CHECK(hipStreamWaitEvent(st, res->events[6 * j + 3], 0));
+            if ((r = after(st, res->events[6 * j + 3]))) return r;
         }
         if (timed) panel_marks.push_back(ev.size());
         if ((r = mark_on(st))) return r;
@@ -2342,8 +2387,7 @@ struct Sweep {
         if (j == 0) {
             if (dev_gate) {  // the bulk streams' gates must not read sync before the prologue has zeroed it
                 BARK_HIP_CHECK(hipEventRecord(res->events[5], main));
-                BARK_HIP_CHECK(hipStreamWaitEvent(panel, res->events[5], 0));
-                BARK_HIP_CHECK(hipStreamWaitEvent(la_stream, res->events[5], 0));
+                if ((r = after(panel, res->events[5])) || (r = after(la_stream, res->events[5]))) return r;
             }
             if ((r = launch_bulk(0))) return r;
             if ((r = launch_bulk(1))) return r;
@@ -2422,8 +2466,14 @@ struct Sweep {
 using namespace bark;
 
 namespace bark {
+static bool env_set(const char *name) {
+    const char *v = std::getenv(name);
+    return v && v[0] && !(v[0] == '0' && v[1] == 0);
+}
 std::atomic<bool> &device_wait_enabled() {
-    static std::atomic<bool> on{std::getenv("BARK_NO_DEVICE_WAIT") == nullptr};
+    // off when asked, and when the environment serialises kernel dispatch: every device-side wait would run into its bound
+    static std::atomic<bool> on{std::getenv("BARK_NO_DEVICE_WAIT") == nullptr && !env_set("AMD_SERIALIZE_KERNEL") &&
+                                !env_set("HIP_LAUNCH_BLOCKING") && !env_set("CUDA_LAUNCH_BLOCKING")};
     return on;
 }
 }  // namespace bark
@@ -2607,6 +2657,7 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
     }
     const size_t t_begin = sw.ev.size();
     if ((rc = sw.mark_on(caller))) return rc;
+    auto chunks = [&]() -> int {
     for (int64_t c0 = 0; c0 < B; c0 += Bc) {  // chunks of Bc resident matrices, one after the other
         const int64_t bc = (B - c0 < Bc) ? (B - c0) : Bc;
         sw.pipelined = pipeline_ok && ((bc % PLAIN_CHUNK_MULTIPLE) != 0 || nrb < PLAIN_MIN_NRB);
@@ -2648,8 +2699,20 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
         if ((rc = prologue(c0, bc))) return rc;
         for (int j = 0; j < nrb; ++j)
             if ((rc = sw.step(j))) return rc;
+        // device-side hand-over: nothing has joined the helper streams to the caller's yet (the last diag_kernel waited for
+        // their counters; after a time-out it did not).  One event join per touched stream and chunk, so that neither the next
+        // chunk's prologue nor the caller's next use of the workspace can overtake a row launch of this one.
+        if (sw.dev_wait) sw.rejoin_helpers();
         if ((rc = epilogue(c0, bc))) return rc;
     }
+    return BARK_OK;
+    };
+    rc = chunks();
+    if (rc) {  // an error return from the middle of a chunk: helper streams may be forked (under capture: unjoined)
+        sw.rejoin_helpers();
+        return rc;
+    }
+    sw.rejoin_helpers();  // (event-join schedules have joined every launch already: nothing is left touched to wait for)
     const size_t t_end = sw.ev.size();
     if ((rc = sw.mark_on(caller))) return rc;
     if (timing) return sw.report(timing, t_begin, t_end, caller);
@@ -2778,6 +2841,7 @@ static int leafspace_run(bark_ctx *ctx, const void *packed, const bark_pack_info
     const bool use_scale = (flags & BARK_MLL_INCLUDE_SCALE) != 0;
 
     if ((rc = leafspace_sumsq(y, (int)N, yy, caller))) return rc;
+    auto chunks = [&]() -> int {
     for (int64_t c0 = 0; c0 < B; c0 += Bc) {
         const int64_t bc = (B - c0 < Bc) ? (B - c0) : Bc;
         bark_pack_info sub = *info;
@@ -2829,6 +2893,10 @@ static int leafspace_run(bark_ctx *ctx, const void *packed, const bark_pack_info
         BARK_LAUNCH_CHECK();
     }
     return BARK_OK;
+    };
+    rc = chunks();
+    sw.rejoin_helpers();  // also on an error return from the middle of a sweep: no helper stream stays forked
+    return rc;
 }
 
 extern "C" {

@@ -23,7 +23,10 @@ int fail(int code, const char *fmt, ...);
                                 __FILE__, __LINE__);                                               \
     } while (0)
 
-#define BARK_LAUNCH_CHECK() BARK_HIP_CHECK(hipGetLastError())
+// Status of the launch just made: hipGetLastError(), or — test hook bark_debug_fail_launch(k) — an injected failure of the
+// k-th checked launch of the process (the kernel itself was enqueued; what is exercised is the error return path).
+hipError_t launch_status();
+#define BARK_LAUNCH_CHECK() BARK_HIP_CHECK(::bark::launch_status())
 
 }  // namespace bark
 
@@ -35,6 +38,7 @@ struct bark_ctx {
     hipStream_t helper2 = nullptr;            // dense sweep: look-ahead launches of the split-K bulk (even steps) / pipelined rows
     hipStream_t helper3 = nullptr;            // dense sweep: look-ahead bulk of the odd steps
     std::vector<hipEvent_t> events;           // fork / join events of the sweep (grown on demand, reused)
+    hipEvent_t rejoin[3] = {nullptr, nullptr, nullptr};  // helper -> caller joins at the end of a chunk / on an error return
     std::vector<hipStream_t> chain_streams;   // multi-chain sampler step: one stream per chain (general shapes)
     std::vector<hipEvent_t> chain_done;
     hipEvent_t chain_fork = nullptr;
@@ -42,6 +46,8 @@ struct bark_ctx {
     size_t ws_bytes = 0;
     int32_t *fault = nullptr;                 // device: set by a leaf walk that met a NaN / inf / negative category
     int32_t *fault_host = nullptr;            // pinned mirror for bark_ctx_status
+    char *stage_host = nullptr;               // pinned staging page of the host-pointer entry points (bark_ctx_upload, ..._host_pair)
+    char *stage_dev = nullptr;                // its device twin
 };
 
 namespace bark {
@@ -52,6 +58,7 @@ int ctx_events(bark_ctx *ctx, size_t n);          // at least n events in ctx->e
 int ctx_chain_streams(bark_ctx *ctx, size_t n);   // at least n chain streams + events
 int set_lds_limits();                             // once per device: kernels with > 64 KiB of dynamic LDS (chol.hip)
 
+constexpr size_t STAGE_BYTES = 64 * 1024;  // bark_ctx::stage_host / stage_dev
 constexpr int NODE_BYTES = 26;          // forest.py:8-19, packed
 constexpr uint32_t LEAF_FLAG = 0x80000000u;
 constexpr uint32_t CAT_FLAG = 0x40000000u;

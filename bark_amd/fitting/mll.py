@@ -131,9 +131,14 @@ def _run(forest, noise, scale, X, y, feat_types, flags, cand=None, timing=None, 
         import warnings
 
         warnings.warn("bark_amd: device-side wait timed out; falling back to event joins for this process", RuntimeWarning)
+        # the timed-out call has joined its helper streams into this one (chol.hip, rejoin_helpers), but the retry rewrites
+        # the same workspace: nothing of the failed call may still be running anywhere on the device
+        torch.cuda.synchronize()
         lib.bark_device_wait(0)
         call()
         bad = info.cpu().numpy()
+        if (bad == -3).any():
+            torch.cuda.synchronize()  # before the error propagates and the workspace is handed to someone else
     _raise_on_info(bad, "kernel matrix")
     return (out, mu, var, cov) if want_cov else (out, mu, var)
 

@@ -228,10 +228,29 @@ class Workload:
             ctypes.byref(timing) if timing is not None else None, self.stream))
         return self.mll_d
 
+    def settle_device_wait(self):
+        """One checked call before anything is timed: chunks of at most 32 matrices hand their row launches over by device-side
+        counters (include/bark_hip.h, bark_device_wait), which needs the library's helper streams to run beside the caller's.
+        Where they cannot (eight processes on one node is the first place that may differ from a one-GPU box) the call
+        reports info = -3 after a bounded wait: drain, switch the mechanism off for the process and repeat — what
+        bark_amd.fitting.mll does for API callers.  -> True if the fallback was taken."""
+        import torch
+
+        self.run()
+        if not bool((self.info_d == -3).any().item()):
+            return False
+        torch.cuda.synchronize()
+        self.lib.bark_device_wait(0)
+        self.run()
+        torch.cuda.synchronize()
+        assert not bool((self.info_d == -3).any().item()), "device-side wait timed out with the mechanism switched off"
+        return True
+
     def device_ms(self, reps, warm=1):
         """Average duration of one production-path call from HIP events on the launch stream."""
         import torch
 
+        self.settle_device_wait()
         for _ in range(warm):
             self.run()
         e = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
@@ -326,6 +345,14 @@ class AbiCollective:
         self.group.close()
 
 
+def device_wait_state(lib) -> str:
+    """on / off: the process-wide switch of the device-side hand-over (chunks of at most 32 matrices; include/bark_hip.h) at the
+    end of the run — `off` with $BARK_NO_DEVICE_WAIT, under a dispatch-serialising environment, or after a time-out."""
+    prev = lib.bark_device_wait(1)
+    lib.bark_device_wait(prev)
+    return "on" if prev else "off"
+
+
 def timed_region(wl, steps, warmup, world, coll, gather):
     """W warm-up steps, then exactly K steps between barrier + synchronize fences; max over ranks."""
     import torch
@@ -337,6 +364,7 @@ def timed_region(wl, steps, warmup, world, coll, gather):
         torch.cuda.synchronize()
 
     out = None
+    wl.settle_device_wait()  # untimed; a device-side wait that cannot work on this node is found (and switched off) here
     for _ in range(warmup):
         out = gather(wl.run())
     fence()
@@ -574,6 +602,7 @@ def worker(args) -> int:
             "collective_backend_requested": (requested if world > 1 else None), "rccl_ranks_seen": rccl_ranks_seen,
             "launched_by": "bench.py" if os.environ.get("BARK_BENCH_WORKER") else "external",
             "timed_path": "production (timing=NULL, no host sync inside the library)",
+            "device_wait": device_wait_state(lib),
         },
         "roofline": {
             "bound": "mfma",

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BARK_HIP_VERSION 200 /* 0.2.0: per-device context (bark_ctx) */
+#define BARK_HIP_VERSION 210 /* 0.2.1: host-pointer entry points (bark_dev_alloc, bark_ctx_upload, ..._host_pair) */
 
 enum {
     BARK_OK = 0,
@@ -60,8 +60,16 @@ const char *bark_last_error(void);
  * device-side progress counter that the diagonal-block kernel waits for (bounded: 2 s), instead of a cross-stream
  * event wait between two kernels of that stream.  It needs the library's helper streams to run beside the caller's;
  * where they cannot (every stream of the process serialised onto one hardware queue), the wait times out and the call
- * reports info_out[b] = -3: switch it off and call again.  Never used under stream capture. */
+ * reports info_out[b] = -3: DRAIN THE DEVICE (hipDeviceSynchronize — the entry point has joined its helper streams into
+ * the caller's stream, so synchronising that stream is enough), switch the mechanism off and call again; the results and the
+ * workspace of the timed-out call are not valid.  A time-out is sticky within a chunk (every later wait gives up at once:
+ * the call costs one 2 s bound, not one per block step).  Off by default when $AMD_SERIALIZE_KERNEL / $HIP_LAUNCH_BLOCKING
+ * serialise dispatch.  Never used under stream capture. */
 int bark_device_wait(int on);
+/* Test hook (tests/test_gpu_context.py): the k-th launch from now on whose status the library checks reports
+ * hipErrorLaunchFailure, so that the error-return paths — helper streams forked, stream capture open — can be exercised on a
+ * healthy device.  k <= 0 switches it off; returns the previous countdown.  Process-wide. */
+long bark_debug_fail_launch(long k);
 /* Host-side self-check of the workgroup -> (matrix, tile) map the sweep kernels share (XCD-aware placement: speed only, but a
  * map that skipped or doubled a pair would be a wrong result): 0 when the launch grid of `ntiles` tiles x `Bc` matrices
  * reaches every pair exactly once, else the number of pairs missed or reached twice.  No GPU needed. */
@@ -84,6 +92,36 @@ size_t bark_ctx_workspace_bytes(const bark_ctx *ctx);
  * this context evaluated a categorical split on a NaN / inf / negative value, where the reference raises inside
  * `1 << int(x)` (forest.py:38).  The MLL / posterior entry points report the same condition as info_out[b] = -1. */
 int bark_ctx_status(bark_ctx *ctx, void *stream, int32_t *cat_fault_out);
+
+/* ---------------------------------------------------------------------------------------
+ * Host-pointer entry points — the ABI for a caller that has no tensor library: the reference's sampler is numba nopython
+ * code (bark_sampler.py:120 `@njit _run_bark_sampler_multichain`, :216 `@njit _step_bark_sampler`), which can call C through
+ * ctypes function pointers with integers, floats and array addresses only.  With these it can hold its chain state in HBM
+ * (bark_sampler.py:153-162: K_inv by bark_mll_batched_hip + BARK_MLL_RHS_IDENTITY) and evaluate every tree proposal
+ * (bark_sampler.py:233-257) from the two host trees it already has.  INTEGRATION.md §4 shows the caller.
+ * ------------------------------------------------------------------------------------- */
+/* hipMalloc / hipFree on the context's device (bark_dev_free synchronises the device, as hipFree does). */
+int bark_dev_alloc(bark_ctx *ctx, size_t bytes, void **ptr_out);
+int bark_dev_free(bark_ctx *ctx, void *ptr);
+/* Host -> device on `stream`; `src_host` may be reused when the call returns (blocks of up to 64 KiB are staged through the
+ * context's pinned page and copied asynchronously, larger ones are copied synchronously). */
+int bark_ctx_upload(bark_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes, void *stream);
+/* Device -> host; synchronises `stream`. */
+int bark_ctx_download(bark_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes, void *stream);
+int bark_stream_sync(bark_ctx *ctx, void *stream);
+/* One tree proposal of `_step_bark_sampler` (bark_sampler.py:233-257) from the trees as the sampler holds them:
+ * pair26 = [forest[tree_idx], new_nodes], 2 x L packed 26-byte records in HOST memory; feat_types HOST int64 (d,);
+ * K_inv (N, N), X (N, d), y (N,) DEVICE; s = sqrt(scale / m) (bark_sampler.py:231).  Packs the pair, stages it through the
+ * context's pinned page, runs bark_tree_swap_eval_hip and returns on the HOST
+ *   scalars_host_out[0] = y'K^-1 y - y'K'^-1 y ,  scalars_host_out[1] = log|K'| - log|K| ,  *r_out = leaves of the pair,
+ * so new_mll = 0.5 (-(quad - scalars[0]) - (logdet + scalars[1])) (quick_inverse.py:38).  An accepted proposal is committed by
+ * bark_lowrank_swap_apply_hip(K_inv, N, *r_out, workspace, K_inv, stream).  workspace >= bark_tree_swap_workspace_bytes(N, 64)
+ * covers every pair this entry point accepts (more than 64 leaves in the pair: BARK_ERR_ARG).  Synchronises `stream`.
+ * NaN / inf scalars: ask bark_lowrank_status_hip (singular update, quick_inverse.py:19,31) and bark_ctx_status. */
+int bark_tree_swap_eval_host_pair(bark_ctx *ctx, const double *K_inv, int64_t N, const void *pair26, int64_t L,
+                                  const int64_t *feat_types, int64_t d, const double *X, double s, const double *y,
+                                  double *scalars_host_out, int64_t *r_out, void *workspace, size_t workspace_bytes,
+                                  void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Forest container  (forest.py:8-19 NODE_RECORD_DTYPE: packed 26-byte records)

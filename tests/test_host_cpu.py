@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.lib()
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.bark_version() == 200
+    assert lib.bark_version() == 210
     assert lib.bark_last_error() == b""
     assert lib.bark_leaf_npad(1) == 128 and lib.bark_leaf_npad(128) == 128 and lib.bark_leaf_npad(129) == 256
 
