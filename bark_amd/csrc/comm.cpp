@@ -79,9 +79,13 @@ int bark_comm_create(const void *id, int rank, int world, int device, void **com
     *comm_out = nullptr;
     int rc = need_api();
     if (rc) return rc;
+    int prev = 0;
+    BARK_HIP_CHECK(hipGetDevice(&prev));
     BARK_HIP_CHECK(hipSetDevice(device));
     Comm c = nullptr;
-    if ((rc = check(api().CommInitRank(&c, world, *static_cast<const UniqueId *>(id), rank), "ncclCommInitRank"))) return rc;
+    rc = check(api().CommInitRank(&c, world, *static_cast<const UniqueId *>(id), rank), "ncclCommInitRank");
+    (void)hipSetDevice(prev);  // the caller's current device is not this function's to change (as bark_ctx_create)
+    if (rc) return rc;
     *comm_out = c;
     return BARK_OK;
 }

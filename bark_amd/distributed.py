@@ -125,12 +125,18 @@ def exchange_unique_id(rank: int, world: int, addr: str, port: int, make_id, tim
 class RcclGroup:
     """One RCCL communicator per process, built and used through the C ABI only (one process per GPU)."""
 
-    def __init__(self, rank: int, world: int, device: int, addr: str = "127.0.0.1", port: int = 29533):
+    def __init__(self, rank: int, world: int, device: int, addr: str = "127.0.0.1", port: int | None = None):
         import ctypes
+        import os
 
         from . import _lib
 
         self._lib, self.rank, self.world = _lib, rank, world
+        self._comm = None
+        if port is None:
+            # next to the launcher's rendezvous port, so that two jobs on one host do not meet on a fixed number (the id is
+            # handed to whoever connects: keep addr on the loopback / a private interface)
+            port = int(os.environ.get("BARK_RCCL_ID_PORT", 0)) or (int(os.environ.get("MASTER_PORT", 29500)) + 33) % 65536 or 29533
         lib = _lib.lib()
 
         def make_id() -> bytes:
@@ -139,8 +145,27 @@ class RcclGroup:
             return buf.raw
 
         uid = exchange_unique_id(rank, world, addr, port, make_id)
-        self._comm = ctypes.c_void_p()
-        _lib.check(lib.bark_comm_create(ctypes.c_char_p(uid), rank, world, device, ctypes.byref(self._comm)))
+        comm = ctypes.c_void_p()
+        _lib.check(lib.bark_comm_create(ctypes.c_char_p(uid), rank, world, device, ctypes.byref(comm)))
+        self._comm, self._device = comm, device
+
+    def _checked(self, t, what: str):
+        """float64, contiguous, on this communicator's GPU — raw pointers cross the ABI, so nothing else may."""
+        import torch
+
+        if not isinstance(t, torch.Tensor) or t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous():
+            raise ValueError(f"{what}: a contiguous float64 CUDA tensor is required")
+        if t.device.index != self._device:
+            raise ValueError(f"{what}: tensor on cuda:{t.device.index}, communicator on cuda:{self._device}")
+        if self._comm is None:
+            raise RuntimeError("RcclGroup is closed")
+        return t
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter teardown
+            pass
 
     def gather_mll(self, local, total: int):
         """`gather_mll` above over this communicator: per-rank blocks (sizes from shard_range) -> (total,) on every rank."""
@@ -152,7 +177,7 @@ class RcclGroup:
         if local.shape[0] != hi - lo:
             raise ValueError(f"rank {self.rank} holds {local.shape[0]} values, expected {hi - lo}")
         widest = max(h - l for l, h in sizes)
-        send = local.contiguous()
+        send = self._checked(local.contiguous(), "gather_mll")
         if send.shape[0] != widest:
             send = torch.zeros(widest, dtype=torch.float64, device=local.device)
             send[: hi - lo] = local
@@ -165,13 +190,14 @@ class RcclGroup:
     def all_reduce(self, t, op: str = "sum"):
         """In place over all ranks (float64 device tensor): 'sum' (mixture moments) or 'max' (the bench's clock)."""
         L = self._lib
+        self._checked(t, "all_reduce")
         L.check(L.lib().bark_allreduce_f64(self._comm, L.ptr(t), t.numel(), 1 if op == "max" else 0, L.stream_ptr()))
         return t
 
     def barrier(self):
         import torch
 
-        one = torch.zeros(1, dtype=torch.float64, device="cuda")
+        one = torch.zeros(1, dtype=torch.float64, device=torch.device("cuda", self._device))
         self.all_reduce(one)
         torch.cuda.synchronize()
 

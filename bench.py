@@ -681,6 +681,9 @@ def sampler_step_probe(args, wl):
     bounds = np.tile(np.array([[0.0, 1.0]]), (wl.d, 1))
     Xd = wl.Xd
     out = {"workload": "N=%d m=%d: 50 tree proposals (device-side Metropolis) + noise/scale proposal + rebuild" % (N, m)}
+    # first: a host round trip per proposal is a latency measurement, and the CPU-oracle legs below leave LAPACK's worker threads
+    # spinning on the box's cores for a while (measured: 4.3 ms per proposal right after them, 0.10-0.15 ms before)
+    out["per_proposal_routes"] = proposal_routes_probe(wl)
     rng = np.random.default_rng(5)
     for nc in (1, 4):
         cur = synthetic.sample_prior_forests(nc, m, bounds, ft, seed=7000)
@@ -788,6 +791,67 @@ def sampler_step_probe(args, wl):
         del cb
     out["small_n_one_chain"] = small
     return out
+
+
+def proposal_routes_probe(wl, n_props=30):
+    """One tree proposal of `_step_bark_sampler` (bark_sampler.py:233-257) with a host round trip per proposal, as the
+    reference's loop is written, through the two routes of INTEGRATION.md §4: (b) `ChainState.propose_tree` (Python + torch
+    tensors: the de-jitted step) and (a) `bark_tree_swap_eval_host_pair` (integer arguments only: what the `@njit` step can
+    call through a ctypes function pointer).  Wall time per proposal, one chain, rejected proposals (no rewrite)."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    import bark_amd.fitting as fit
+    from bark_amd import _lib, synthetic
+
+    N, m, d = wl.N, wl.m, wl.d
+    bounds = np.tile(np.array([[0.0, 1.0]]), (d, 1))
+    cur = synthetic.sample_prior_forests(1, m, bounds, wl.ft, seed=7000)[0]
+    prop = synthetic.sample_prior_forests(1, m, bounds, wl.ft, seed=8000)[0]
+    st = fit.ChainState.from_forest(cur, 0.1, 1.0, wl.Xd, wl.y, wl.ft)
+    n_props = min(n_props, m)
+    vals_b = []
+    st.propose_tree(cur[0], prop[0], wl.Xd, wl.ft, 1.0, m)  # warm-up
+    t = time.perf_counter()
+    for ti in range(n_props):
+        vals_b.append(st.propose_tree(cur[ti], prop[ti], wl.Xd, wl.ft, 1.0, m))
+    route_b = (time.perf_counter() - t) / n_props
+    # route (a): everything below is int / float / array-address arguments
+    lib = _lib.lib()
+    ft = np.ascontiguousarray(wl.ft, dtype=np.int64)
+    ws = torch.empty(int(lib.bark_tree_swap_workspace_bytes(N, 64)), dtype=torch.uint8, device=wl.Xd.device)
+    scalars, r_out = np.empty(2), np.zeros(1, dtype=np.int64)
+    pair = np.empty((2, cur.shape[1]), dtype=cur.dtype)
+    k_inv, x_dev, y_dev, ws_dev, ctx = st.K_inv.data_ptr(), wl.Xd.data_ptr(), st.y.data_ptr(), ws.data_ptr(), _lib.ctx()
+    stream = _lib.stream_ptr()
+    s_sqrtm = float(np.sqrt(1.0 / m))
+
+    def host_pair(ti):
+        pair[0], pair[1] = cur[ti], prop[ti]
+        _lib.check(lib.bark_tree_swap_eval_host_pair(ctx, k_inv, N, pair.ctypes.data, pair.shape[1], ft.ctypes.data, d, x_dev, s_sqrtm,
+                                                     y_dev, scalars.ctypes.data, r_out.ctypes.data, ws_dev, ws.numel(), stream))
+        return 0.5 * (-(st.quad - scalars[0]) - (st.logdet + scalars[1]))
+
+    host_pair(0)
+    vals_a = []
+    t = time.perf_counter()
+    for ti in range(n_props):
+        vals_a.append(host_pair(ti))
+    route_a = (time.perf_counter() - t) / n_props
+    assert np.allclose(vals_a, vals_b, rtol=1e-12, atol=1e-9), "the two routes disagree"
+    # the pure host share of route (a): packing the pair (no device work)
+    info = _lib.PackInfo()
+    t = time.perf_counter()
+    for ti in range(n_props):
+        pair[0], pair[1] = cur[ti], prop[ti]
+        lib.bark_forest_pack_info(pair.ctypes.data, 1, 2, pair.shape[1], ft.ctypes.data, d, C.byref(info))
+    pack = (time.perf_counter() - t) / n_props
+    return {"workload": "N=%d m=%d, %d proposals, one chain, one host round trip per proposal" % (N, m, n_props),
+            "chainstate_propose_tree_ms": 1e3 * route_b, "host_pair_entry_point_ms": 1e3 * route_a,
+            "host_share_of_the_entry_point_ms (pair copy + pack_info, Python call included)": 1e3 * pack,
+            "routes_agree_rtol": 1e-12}
 
 
 def fitting_loop_probe(calls=100):

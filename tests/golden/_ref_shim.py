@@ -56,7 +56,12 @@ def install():
             "types", "typed", "typeof",
         ):
             setattr(numba, name, placeholder)
-        numba.__getattr__ = lambda name: placeholder  # any other type name used in a jitclass spec
+        def _any_type(name):  # any other type name used in a jitclass spec — but no dunder (inspect asks modules for __file__)
+            if name.startswith("__"):
+                raise AttributeError(name)
+            return placeholder
+
+        numba.__getattr__ = _any_type
         experimental = types.ModuleType("numba.experimental")
         experimental.jitclass = _identity_decorator
         numba.experimental = experimental

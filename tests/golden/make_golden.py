@@ -10,9 +10,14 @@ functions (`bark.forest.*`, `bark.fitting.quick_inverse.*`,
 through `_ref_shim.py` (identity-njit == the reference's NUMBA_DISABLE_JIT mode),
 plus `numpy.linalg.inv/slogdet` exactly where the reference calls them
 (`examples/mcmc/mcmc_record_mll.py:57-74`, `bark/tree_kernels/tree_gps.py:80-113`,
-`bark/fitting/bark_sampler.py:153-162`).  `forest_predict` itself cannot be imported
-(gpytorch/beartype absent), so G6 evaluates its 12 numpy lines on top of the
-reference's `batched_forest_gram_matrix`; this is recorded in the fixture's `meta`.
+`bark/fitting/bark_sampler.py:153-162`).  Since round 4 `forest_predict` /
+`mixture_of_gaussians_as_normal` (`bark/tree_kernels/tree_gps.py:80-131`) and the example's
+`mll` (`examples/mcmc/mcmc_record_mll.py:57-74`) are the reference's OWN functions too: the
+modules import under placeholder `gpytorch` / `beartype` / `bofire` modules (they only need
+base classes and type names at import) and `get_feature_types_array` is the reference's
+(`bofire_mixed/domain.py:55-65`) on a minimal domain object.  The transcriptions that
+rounds 1-3 used (`mll_example`, `predict_lines` below) are kept only as a cross-check that
+must agree bit for bit; every fixture's `meta.src` names the imported function.
 
 Forests are stored as raw bytes of the packed 26-byte NODE_RECORD_DTYPE
 (`forest.py:8-19`) so the fixtures do not depend on numpy dtype pickling.
@@ -216,10 +221,10 @@ def g3_prior_mixed():
         K_nn = F.batched_forest_gram_matrix_no_null(forest, X, X, ft)
         save(f"g3_prior_mixed_n{N}",
              {"src": "bark_prior_sampler.py:15-65 + forest.py:58-111 + mcmc_record_mll.py:57-74 "
-                     "+ bark_sampler.py:153-162", "N": N, "m": m, "B": B},
+                     "+ bark_sampler.py:153-162", "mll_example_src": MLL_EXAMPLE_SRC, "N": N, "m": m, "B": B},
              forest=raw(forest), X=X, y=y, bounds=bounds, feat_types=ft,
              noise=noise, scale=scale, leaves=leaves, K=K, K_no_null=K_nn,
-             mll_example=mll_example(forest, noise, X, y, ft),
+             mll_example=mll_example_ref(forest, noise, X, y, ft),
              mll_sampler=mll_sampler(forest, noise, scale, X, y, ft))
 
 
@@ -231,9 +236,9 @@ def g4_all_null():
     K = F.batched_forest_gram_matrix(forest, X, X, ft)
     K_nn = F.batched_forest_gram_matrix_no_null(forest, X, X, ft)
     noise = np.array([0.3])
-    save("g4_all_null", {"src": "forest.py:114-117 empty forest; K==1 everywhere"},
+    save("g4_all_null", {"src": "forest.py:114-117 empty forest; K==1 everywhere", "mll_example_src": MLL_EXAMPLE_SRC},
          forest=raw(forest), X=X, y=y, feat_types=ft, leaves=leaves, K=K, K_no_null=K_nn,
-         noise=noise, mll_example=np.atleast_1d(mll_example(forest, noise, X, y, ft)))
+         noise=noise, mll_example=np.atleast_1d(mll_example_ref(forest, noise, X, y, ft)))
 
 
 def g5_boundaries():
@@ -287,16 +292,24 @@ def g6_predict():
     noise = np.array([0.1, 0.07, 0.15, 0.12])
     scale = np.array([1.0, 0.8, 1.2, 0.95])
     # shape (chains=2, samples=2, ...) to exercise the flatten at tree_gps.py:88-90
-    mu, var_diag, var_full = predict_lines(forest, noise, scale, X, y, cand, ft)
+    tg, _, make_domain = reference_predict_modules()
+    model = tg.BARKModel(forest.reshape(2, 2, m, -1), noise.reshape(2, 2), scale.reshape(2, 2))
+    dom = make_domain(ft)
+    mu, var_diag = tg.forest_predict(model, (X, y), cand, dom, diag=True)
+    mu_f, var_full = tg.forest_predict(model, (X, y), cand, dom, diag=False)
+    mu_y, var_y = tg.mixture_of_gaussians_as_normal(mu, var_diag)
+    # cross-check: the transcription of rounds 1-3 must be the same numbers, bit for bit
+    t_mu, t_diag, t_full = predict_lines(forest, noise, scale, X, y, cand, ft)
+    assert np.array_equal(mu, t_mu) and np.array_equal(mu_f, t_mu) and np.array_equal(var_diag, t_diag) and np.array_equal(var_full, t_full)
+    assert np.array_equal(mu_y, np.mean(mu, axis=0)) and np.array_equal(var_y, np.mean(var_diag + mu**2, axis=0) - mu_y**2)
     K_xX = F.batched_forest_gram_matrix(forest, cand, X, ft)
-    mu_y = np.mean(mu, axis=0)
-    var_y = np.mean(var_diag + mu**2, axis=0) - mu_y**2  # tree_gps.py:129-131
     save("g6_predict",
-         {"src": "tree_gps.py:87-112 evaluated on reference batched_forest_gram_matrix (forest_predict "
-                 "itself needs gpytorch at import); mixture: tree_gps.py:129-131",
+         {"src": "bark.tree_kernels.tree_gps.forest_predict (tree_gps.py:80-113; diag=True -> mu, var; diag=False -> var_full) "
+                 "and mixture_of_gaussians_as_normal (tree_gps.py:116-131), imported from /root/reference/src under placeholder "
+                 "gpytorch / beartype / bofire modules; feat_types from bofire_mixed.domain.get_feature_types_array",
           "N": N, "C": C, "B": B},
          forest=raw(forest.reshape(2, 2, m, -1)), noise=noise.reshape(2, 2), scale=scale.reshape(2, 2),
-         X=X, y=y, cand=cand, feat_types=ft, K_xX=K_xX, mu=mu, var=var_diag, var_full=var_full,
+         X=X, y=y, cand=cand, feat_types=ft, K_xX=K_xX, mu=mu, var=np.ascontiguousarray(var_diag), var_full=var_full,
          mix_mu=mu_y, mix_var=var_y)
 
 
@@ -394,10 +407,10 @@ def g8_batched_mll():
     scale = np.array([1.0, 1.1, 0.9, 1.05])
     K = F.batched_forest_gram_matrix(forest, X, X, ft)
     save("g8_batched_mll",
-         {"src": "mcmc_record_mll.py:57-74 and bark_sampler.py:153-162; d = 5 cont + 2 int + 1 cat",
+         {"src": "mcmc_record_mll.py:57-74 and bark_sampler.py:153-162; d = 5 cont + 2 int + 1 cat", "mll_example_src": MLL_EXAMPLE_SRC,
           "N": N, "B": B},
          forest=raw(forest), X=X, y=y, bounds=bounds, feat_types=ft, noise=noise, scale=scale, K=K,
-         mll_example=mll_example(forest, noise, X, y, ft),
+         mll_example=mll_example_ref(forest, noise, X, y, ft),
          mll_sampler=mll_sampler(forest, noise, scale, X, y, ft))
 
 
@@ -454,6 +467,83 @@ def _bofire_stubs():
         spec.loader.exec_module(mod)
 
 
+_REF_PREDICT = None
+
+
+def reference_predict_modules():
+    """-> (bark.tree_kernels.tree_gps, examples/mcmc/mcmc_record_mll.py as a module, make_domain).  The reference's modules,
+    imported unmodified: `tree_gps.py` needs gpytorch only as the base class of LeafGP / TreeAgreementKernel (never
+    instantiated here), beartype for `Optional`, bofire for the `Domain` annotation; the example script needs a handful of
+    bofire / bofire_mixed names at import that its `mll` function never touches.  `make_domain(feat_types)` builds the
+    object `get_feature_types_array` (the reference's own, bofire_mixed/domain.py:55-65) is applied to."""
+    global _REF_PREDICT
+    if _REF_PREDICT is not None:
+        return _REF_PREDICT
+    import importlib.util
+    import typing
+
+    _bofire_stubs()
+
+    def _mod(name, **attrs):
+        mod = sys.modules.get(name) or types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(mod, k, v)
+        sys.modules[name] = mod
+        return mod
+
+    base = type("_Base", (), {"__init__": lambda self, *a, **k: None})
+    _mod("gpytorch", models=types.SimpleNamespace(ExactGP=base), kernels=types.SimpleNamespace(Kernel=base, ScaleKernel=base),
+         means=types.SimpleNamespace(ZeroMean=base, ConstantMean=base), distributions=types.SimpleNamespace(MultivariateNormal=base),
+         likelihoods=types.SimpleNamespace(GaussianLikelihood=base))
+    _mod("beartype")
+    _mod("beartype.typing", Optional=typing.Optional)
+    import bark.tree_kernels.tree_gps as tg
+
+    obj = type("_P", (), {})
+    _mod("bofire.data_models.strategies")
+    _mod("bofire.data_models.strategies.api", RandomStrategy=obj)
+    _mod("bofire_mixed.benchmarks", DatasetBenchmark=obj, map_benchmark=lambda *a, **k: None)
+    _mod("bofire_mixed.data_models")
+    _mod("bofire_mixed.data_models.strategies")
+    _mod("bofire_mixed.data_models.strategies.mapper", strategy_map=lambda *a, **k: None)
+    _mod("bofire_mixed.data_models.surrogates")
+    _mod("bofire_mixed.data_models.surrogates.api", BARKSurrogate=obj)
+    _mod("bofire_mixed.data_models.surrogates.mapper", surrogate_map=lambda *a, **k: None)
+    import bark.fitting.bark_sampler  # noqa: F401  (DataT / ModelT of the example's annotations)
+
+    spec = importlib.util.spec_from_file_location("ref_mcmc_record_mll", "/root/reference/examples/mcmc/mcmc_record_mll.py")
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)  # defines functions only; its __main__ block does not run
+
+    # the feature classes the reference's get_feature_types_array tests with isinstance — those of the bofire_mixed.domain
+    # module object tree_gps and the example imported (g7 loads that file a second time with classes of its own)
+    assert ex.get_feature_types_array is tg.get_feature_types_array
+    gl = tg.get_feature_types_array.__globals__
+    by_type = {CAT: gl["CategoricalInput"], INT: gl["DiscreteInput"], CONT: gl["ContinuousInput"]}
+
+    def make_domain(feat_types):
+        inputs = types.SimpleNamespace(get=lambda: [by_type[int(t)]() for t in feat_types])
+        dom = types.SimpleNamespace(inputs=inputs)
+        assert np.array_equal(tg.get_feature_types_array(dom), feat_types)
+        return dom
+
+    _REF_PREDICT = (tg, ex, make_domain)
+    return _REF_PREDICT
+
+
+MLL_EXAMPLE_SRC = ("mll() of /root/reference/examples/mcmc/mcmc_record_mll.py:57-74, the module loaded by path under placeholder "
+                   "bofire modules; feat_types through bofire_mixed.domain.get_feature_types_array")
+
+
+def mll_example_ref(forest, noise, X, y, feat_types):
+    """examples/mcmc/mcmc_record_mll.py:57-74 — the reference's function itself; the transcription must agree bit for bit."""
+    _, ex, make_domain = reference_predict_modules()
+    scale = np.ones_like(np.asarray(noise, dtype=np.float64))  # the example's mll unpacks but never uses `scale`
+    out = ex.mll((forest, noise, scale), (X, y), make_domain(feat_types))
+    assert np.array_equal(np.atleast_1d(out), np.atleast_1d(mll_example(forest, noise, X, y, feat_types)))
+    return out
+
+
 def g10_mcmc_posterior_forests():
     """Forests produced by the reference's own Metropolis-Hastings sampler
     (bark_sampler.py:121-284 `_run_bark_sampler_multichain`): 2 chains x 3 samples after warm-up, on a mixed
@@ -483,12 +573,12 @@ def g10_mcmc_posterior_forests():
     K_nn = F.batched_forest_gram_matrix_no_null(flat, X, X, ft)
     inactive_internal = int(((flat["active"] == 0) & (flat["is_leaf"] == 0) & (flat["left"] > 0)).sum())
     save("g10_mcmc_posterior_forests",
-         {"src": "bark_sampler.py:121-284 run under the shim (np.random.seed(1010)); forest.py:58-111; "
+         {"mll_example_src": MLL_EXAMPLE_SRC, "src": "bark_sampler.py:121-284 run under the shim (np.random.seed(1010)); forest.py:58-111; "
                  "mcmc_record_mll.py:57-74; bark_sampler.py:153-162",
           "inactive_internal_slots": inactive_internal, "active_nodes_max": int(flat["active"].sum(-1).max())},
          forest=raw(node_samples), noise=noise_samples, scale=scale_samples, X=X, y=y, bounds=bounds, feat_types=ft,
          leaves=leaves, K=K, K_no_null=K_nn,
-         mll_example=mll_example(node_samples, noise_samples, X, y, ft),
+         mll_example=mll_example_ref(node_samples, noise_samples, X, y, ft),
          mll_sampler=mll_sampler(flat, noise_samples.reshape(-1), scale_samples.reshape(-1), X, y, ft))
 
 

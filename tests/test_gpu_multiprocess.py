@@ -82,4 +82,69 @@ def test_rccl_through_the_c_abi_world_of_one():
     g.all_reduce(buf, "max")
     g.barrier()
     assert buf.tolist() == [2.0, -3.0, 5.5]
+    # raw pointers cross the ABI: anything but a contiguous float64 tensor on the communicator's GPU is refused up front
+    with pytest.raises(ValueError):
+        g.all_reduce(buf.float())
+    with pytest.raises(ValueError):
+        g.all_reduce(buf.cpu())
+    with pytest.raises(ValueError):
+        g.all_reduce(torch.zeros((4, 2), dtype=torch.float64, device="cuda")[:, 0])
+    assert torch.cuda.current_device() == 0
     g.close()
+    with pytest.raises(RuntimeError):
+        g.all_reduce(buf)
+
+
+_ABI_VS_TORCH = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import torch
+import torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+dist.init_process_group("nccl", rank=rank, world_size=world)
+from bark_amd.distributed import RcclGroup, shard_range
+g = RcclGroup(rank, world, rank)
+total = 11  # ragged: 6 + 5
+lo, hi = shard_range(total, rank, world)
+local = (torch.arange(lo, hi, dtype=torch.float64, device="cuda") + 0.25) * (rank + 1)
+via_abi = g.gather_mll(local, total)
+even = torch.full((4,), float(rank), dtype=torch.float64, device="cuda")  # equal blocks: against dist.all_gather itself
+pieces = [torch.empty(4, dtype=torch.float64, device="cuda") for _ in range(world)]
+dist.all_gather(pieces, even)
+assert torch.equal(g.gather_mll(even, 4 * world), torch.cat(pieces))
+ref = torch.cat([(torch.arange(*shard_range(total, r, world), dtype=torch.float64, device="cuda") + 0.25) * (r + 1) for r in range(world)])
+assert torch.equal(via_abi, ref), (via_abi, ref)
+a = torch.full((5,), float(rank + 1), dtype=torch.float64, device="cuda")
+b = a.clone()
+g.all_reduce(a)
+dist.all_reduce(b)
+assert torch.equal(a, b)
+g.all_reduce(a, "max")
+g.barrier()
+g.close()
+dist.destroy_process_group()
+print("abi-vs-torch ok", rank)
+"""
+
+
+def test_rccl_abi_matches_torch_distributed_two_ranks():
+    """the hand-declared RCCL ABI (csrc/comm.cpp) against torch.distributed's nccl backend with TWO ranks on two
+    GPUs — the first place the declarations can be wrong in a way a world of one does not show.  Needs a node with two
+    GPUs: skipped on the one-GPU boxes this suite normally runs on (the RCCL leg has never run with more than one rank)."""
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs on one node")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", _ABI_VS_TORCH.format(root=root)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-800:] for o in outs]
