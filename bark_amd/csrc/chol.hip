@@ -1307,7 +1307,18 @@ __global__ __launch_bounds__(THREADS, 2) void row_kernel(Mats p, int j, int kdon
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
     int b, t;
-    if (!xcd_map(blockIdx.x, n_tiles, p.Bc, b, t)) return;
+    if (syrk == 2) {  // the square tiles first (XCD-aware map over n_right tiles), then one SYRK workgroup per matrix: launch_rows
+        const int first_diag = (int)xcd_grid(n_right, p.Bc);  // a multiple of 8: workgroup id % 8 == b % 8 in the tail as well
+        if ((int)blockIdx.x >= first_diag) {
+            b = (int)blockIdx.x - first_diag;
+            t = n_right;
+            if (b >= p.Bc) return;
+        } else if (!xcd_map(blockIdx.x, n_right, p.Bc, b, t)) {
+            return;
+        }
+    } else if (!xcd_map(blockIdx.x, n_tiles, p.Bc, b, t)) {
+        return;
+    }
     const Lane q = lane_of(tid);
     double *Ab = p.A + (size_t)b * p.bstride;
     const int rb = t < n_right ? j : j + 1;
@@ -1860,11 +1871,17 @@ constexpr int PIPE_MIN_NRB = BARK_PIPE_MIN_NRB;  // fewer block rows: plain sche
 #define BARK_PLAIN_CHUNK_MULTIPLE 256
 #endif
 constexpr int PLAIN_CHUNK_MULTIPLE = BARK_PLAIN_CHUNK_MULTIPLE;  // chunks of a multiple of this many matrices (and >= PLAIN_MIN_NRB block rows): plain
-// round 4, with the diagonal tile as a SYRK in the pipelined launches — plain | pipelined, ms, same box: N = 2200 x 256 19.31 | 18.63,
-// N = 3000 x 256 42.84 | 41.95, N = 4096 x 256 96.2 / 96.7 | 95.8 / 97.1 (a tie, as before), N = 4096 x 512 192.5 | 193.4,
-// N = 8192 x 256 726.8 | 743.3: the rule used to be 16 block rows
+// round 4 (diagonal tile as a SYRK after the square tiles, in both schedules) — plain | pipelined, ms, same box: N = 2200 x 256
+// 18.21 | 18.44, N = 3000 x 256 40.70 | 41.10, N = 4096 x 256 92.45 | 93.05, N = 1536 x 256 (12 block rows) 6.29 | 6.24,
+// N = 1536 x 512 11.97 | 12.24, N = 1100 x 256 3.12 | 3.13: the rule stays at 16 block rows
 #ifndef BARK_PLAIN_MIN_NRB
-#define BARK_PLAIN_MIN_NRB 32
+#define BARK_PLAIN_MIN_NRB 16
+#endif
+#ifndef BARK_PIPE_SYRK_MODE
+#define BARK_PIPE_SYRK_MODE 2  // pipelined schedule's row launches: 1 = SYRK workgroup in its matrix's run of tiles, 2 = after all square tiles
+#endif
+#ifndef BARK_PLAIN_SYRK_MODE
+#define BARK_PLAIN_SYRK_MODE 2  // 0: square diagonal tile; 2: SYRK workgroups after all square tiles (launch_rows)
 #endif
 constexpr int PLAIN_MIN_NRB = BARK_PLAIN_MIN_NRB;
 #ifndef BARK_SOLVE_NARROW_MAX_WGS
@@ -2062,13 +2079,23 @@ struct Sweep {
         return BARK_OK;
     }
 
-    // syrk: the partial diagonal tile as a SYRK (syrk_tile) — 7/16 less work in one workgroup of every matrix.  Pays where row
-    // launches overlap (pipelined schedule: N = 4096 x 192 71.8 -> 70.5 ms, N = 2200 x 256 19.1 -> 18.6, B = 256 95.8 -> 94.1);
-    // in the plain schedule of a chunk that is a multiple of the CU count every workgroup of a launch has the same length and
-    // the launch advances in lock step — the co-running tiles of a matrix stream the shared A panel through L2 at the same k —
-    // and one shorter workgroup per matrix breaks that: N = 4096 x 256 94.5 -> 97.4 ms (profiles/r04/headline_power_wall.txt)
+    // syrk != 0: the partial diagonal tile as a SYRK (syrk_tile) — 7/16 less work in one workgroup of every matrix.
+    //   1  the SYRK workgroup sits in its matrix's run of tiles.  In the PLAIN schedule of a chunk that is a multiple of the CU
+    //      count every workgroup of a launch is equally long and the launch advances in lock step (the co-running tiles of a
+    //      matrix stream their shared A panel through L2 at the same k); one short workgroup per matrix staggers every later
+    //      round: N = 4096 x 256 94.5 -> 97.4 ms.  Pipelined launches (no lock step to lose) gained 1-2 % from it.
+    //   2  the SYRK workgroups of all matrices come LAST in the launch, after every square tile (needs the diagonal tile in
+    //      the launch: n_tiles == n_right + 1): the square tiles keep their lock step and the short workgroups fill — or are —
+    //      the last round.  Plain, same box, square diagonal tile | this: N = 4096 x 256 95.3 | 92.4 ms, x 512 189.3 | 183.6,
+    //      N = 4200 x 256 104.6 | 101.5, N = 8192 x 256 715 | 703; pipelined, mode 1 | 2: N = 4096 x 64 24.04 | 23.67, x 192
+    //      70.6 | 69.9, N = 2200 x 256 18.54 | 18.32.  Shipped in both schedules (BARK_PLAIN_SYRK_MODE, BARK_PIPE_SYRK_MODE).
+    //   (a third form — the SYRK workgroups as a launch of their own on another stream, released with solve(j), which does not
+    //   need them — measured slower: 92.7-96.0 against 91.4-92.5 ms; profiles/r04/headline_power_wall.txt item 6)
     int launch_rows(hipStream_t st, int j, int kdone, int n_right, int n_tiles, int syrk) {
-        const dim3 g(xcd_grid(n_tiles, p.Bc)), blk(THREADS);
+        if (syrk == 2 && n_tiles != n_right + 1) syrk = 0;
+        const unsigned diag_wgs = (unsigned)(NXCD * ((p.Bc + NXCD - 1) / NXCD));
+        const unsigned grid = syrk == 2 ? xcd_grid(n_right, p.Bc) + diag_wgs : xcd_grid(n_tiles, p.Bc);
+        const dim3 g(grid), blk(THREADS);
         if (!fused)
             hipLaunchKernelGGL(row_kernel<0>, g, blk, GEMM_LDS, st, p, j, kdone, n_right, n_tiles, syrk);
         else if (rep == REP_BITS)
@@ -2296,7 +2323,10 @@ struct Sweep {
                 int tail, St;
                 ragged_tail(j, n_tiles, tail, St);
                 if (tail > 0) {
-                    if ((r = launch_rows(ps, j, j, n_right, tail, 0))) return r;
+                    const int lockstep = (tail == n_tiles && p.Bc % PLAIN_CHUNK_MULTIPLE == 0) ? BARK_PLAIN_SYRK_MODE : 0;
+                    if ((r = launch_rows(ps, j, j, n_right, tail, lockstep))) {
+                        return r;
+                    }
                 }
                 if (tail < n_tiles) {
                     if ((r = launch_split(ps, j, 0, j, St, 0, St, tail, n_tiles - tail))) return r;
@@ -2369,7 +2399,7 @@ struct Sweep {
         if (S >= 2) {
             if ((r = launch_split(st, j, 0, k, S, 0, S))) return r;
             if ((r = launch_reduce(st, j, S))) return r;
-        } else if ((r = launch_rows(st, j, k, ncb - j - 1, nt, 1))) {
+        } else if ((r = launch_rows(st, j, k, ncb - j - 1, nt, BARK_PIPE_SYRK_MODE))) {
             return r;
         }
         if ((r = mark_on(st))) return r;

@@ -50,8 +50,9 @@ def test_c3_b256_plain_schedule():
     """configs[2], the headline shape exactly: N = 4096, d = 8, m = 50, B = 256 forests seeded 4096 + b, noise
     U[0.05, 0.15) (examples/mcmc/mcmc_record_mll.py:57-74 convention).  256 resident matrices of 32 block
     rows is the one shape class that takes Sweep's PLAIN schedule with ragged-round splitting off (bc % 256 == 0 and
-    nrb >= 32).  First / middle / last sample against the oracle's LU route, bit-reproducibility of the call, and
-    agreement with the pipelined schedule (chunk = 64: row launches with the diagonal tile as a SYRK)."""
+    nrb >= 16; since round 4 its row launches end with one SYRK workgroup per matrix for the diagonal tile).  First / middle
+    / last sample against the oracle's LU route, bit-reproducibility of the call, and agreement with the pipelined schedule
+    (chunk = 64)."""
     import torch
 
     import bark_amd.fitting as fit
@@ -76,8 +77,8 @@ def test_c3_b256_plain_schedule():
 
 
 def test_n2200_b256_one_chunk_of_256():
-    """256 resident matrices of 18 block rows, ragged N, mixed feature types, scale included: the plain schedule until
-    round 3, since round 4 (fewer than 32 block rows) the pipelined one with SYRK diagonal tiles in chunks of every size."""
+    """A second shape of the plain schedule's class (18 block rows >= 16, 256 resident matrices), ragged N, mixed feature
+    types, scale included; the chunk = 96 call is the pipelined schedule on the same forests."""
     import bark_amd.fitting as fit
     from bark_amd import synthetic as syn
     from oracle import oracle as orc
@@ -126,7 +127,7 @@ def test_mll_tolerance_as_the_kernel_matrix_approaches_singularity(noise):
 
 
 def test_plain_schedule_n4200_b256():
-    """A second shape of the plain schedule's class (33 block rows, 256 resident matrices), ragged N (4200 = 32 x 128 + 104:
+    """A third shape of the plain schedule's class (33 block rows, 256 resident matrices), ragged N (4200 = 32 x 128 + 104:
     identity padding in the last block row), mixed feature types, scale included."""
     import bark_amd.fitting as fit
     from bark_amd import synthetic as syn
