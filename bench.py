@@ -353,6 +353,67 @@ def device_wait_state(lib) -> str:
     return "on" if prev else "off"
 
 
+class PowerSampler:
+    """Socket power and shader clock of THIS process's card while the timed steps run (hwmon of the card whose render node the
+    process may open; a second thread, 20 ms period, sysfs reads only).  The c3 sweep runs at the socket power cap
+    (profiles/r04/headline_power_wall.txt): these three numbers put that on record in the line itself.  Returns None when the
+    box exposes no readable hwmon node."""
+
+    def __init__(self):
+        import glob
+
+        self.hw = None
+        for rn in glob.glob("/sys/class/drm/renderD*"):
+            if not os.access("/dev/dri/" + os.path.basename(rn), os.R_OK | os.W_OK):
+                continue
+            dev = os.path.realpath(os.path.join(rn, "device"))
+            cands = glob.glob(os.path.join(dev, "hwmon", "hwmon*"))
+            if cands and os.path.exists(os.path.join(cands[0], "power1_input")):
+                if self.hw is not None:
+                    self.hw = None  # more than one card is ours: no way to say which one this rank drives
+                    break
+                self.hw = cands[0]
+        self.rows, self._stop, self._th = [], None, None
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.hw, name)) as f:
+                return float(f.read())
+        except (OSError, ValueError):
+            return None
+
+    def start(self):
+        import threading
+
+        if self.hw is None:
+            return
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                pw, fq = self._read("power1_input"), self._read("freq1_input")
+                if pw is not None and fq is not None:
+                    self.rows.append((pw / 1e6, fq / 1e6))
+                time.sleep(0.02)
+
+        self._th = threading.Thread(target=loop, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        if self._th is None:
+            return None
+        self._stop.set()
+        self._th.join()
+        rows = self.rows[len(self.rows) // 5:]  # the first fifth: ramp-up of the averaged power reading
+        if len(rows) < 5:
+            return None
+        med = lambda v: sorted(v)[len(v) // 2]
+        cap = self._read("power1_cap")
+        return {"socket_power_w_median": med([r[0] for r in rows]), "socket_power_cap_w": cap / 1e6 if cap else None,
+                "sclk_mhz_median": med([r[1] for r in rows]), "samples": len(rows),
+                "source": "hwmon power1_input / freq1_input / power1_cap of this rank's card, sampled every 20 ms over the timed steps"}
+
+
 def timed_region(wl, steps, warmup, world, coll, gather):
     """W warm-up steps, then exactly K steps between barrier + synchronize fences; max over ranks."""
     import torch
@@ -369,6 +430,9 @@ def timed_region(wl, steps, warmup, world, coll, gather):
         out = gather(wl.run())
     fence()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * steps)]
+    power = PowerSampler() if world == 1 else None  # (one card per box here; with several ranks each would need its own card's node)
+    if power:
+        power.start()
     t0 = time.perf_counter()
     for i in range(steps):
         ev[2 * i].record()      # HIP events on the launch stream, around the library call only
@@ -377,6 +441,7 @@ def timed_region(wl, steps, warmup, world, coll, gather):
         out = gather(mll)
     fence()
     elapsed = time.perf_counter() - t0
+    timed_region.power = power.stop() if power else None
     if world > 1:
         elapsed = coll.max_over_ranks(elapsed, wl.Xd.device)
     call_ms = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(steps)) / steps
@@ -539,6 +604,7 @@ def worker(args) -> int:
     # ---- synthetic inputs: same X, y on every rank; rank r owns forests offset .. offset+B-1
     wl = Workload(N, d, m, B, seed_base=N, rank_offset=offset, chunk=args.chunk, noise_seed=rank)
     elapsed, call_ms, all_mll = timed_region(wl, args.steps, args.warmup, world, coll, make_gather(total))
+    power_c3 = getattr(timed_region, "power", None)
     mll_host = wl.check()
     assert all_mll.shape[0] == total and bool(torch.isfinite(all_mll).all())
 
@@ -617,6 +683,7 @@ def worker(args) -> int:
             "traffic_unit": "bytes of HBM traffic per step (one Cholesky launch sequence)",
             "traffic_source": traffic if traffic else "no committed PMC profile matches this build (csrc digest %s) "
                                                       "and workload" % csrc_digest(),
+            "power": power_c3,
             "algorithmic_flops_per_step": chol_flops,
             "call_ms": call_ms,
             "instrumented_step_ms": breakdown,
