@@ -236,6 +236,8 @@ class Workload:
         bark_amd.fitting.mll does for API callers.  -> True if the fallback was taken."""
         import torch
 
+        if self.Bc > 32 or device_wait_state(self.lib) == "off":  # chunks of more than 32 matrices never use the mechanism
+            return False
         self.run()
         if not bool((self.info_d == -3).any().item()):
             return False
