@@ -361,10 +361,24 @@ class PowerSampler:
     (profiles/r04/headline_power_wall.txt): these three numbers put that on record in the line itself.  Returns None when the
     box exposes no readable hwmon node."""
 
-    def __init__(self):
+    def __init__(self, device_index=None):
         import glob
 
         self.hw = None
+        if device_index is not None:  # the PCI address torch reports for this rank's device names the card directly
+            try:
+                import torch
+
+                pr = torch.cuda.get_device_properties(device_index)
+                addr = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+                cands = glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % addr)
+                if cands and os.path.exists(os.path.join(cands[0], "power1_input")):
+                    self.hw = cands[0]
+            except Exception:  # older torch: no pci_* fields
+                self.hw = None
+        self.rows, self._stop, self._th = [], None, None
+        if self.hw is not None:
+            return
         for rn in glob.glob("/sys/class/drm/renderD*"):
             if not os.access("/dev/dri/" + os.path.basename(rn), os.R_OK | os.W_OK):
                 continue
@@ -375,7 +389,6 @@ class PowerSampler:
                     self.hw = None  # more than one card is ours: no way to say which one this rank drives
                     break
                 self.hw = cands[0]
-        self.rows, self._stop, self._th = [], None, None
 
     def _read(self, name):
         try:
@@ -432,7 +445,7 @@ def timed_region(wl, steps, warmup, world, coll, gather):
         out = gather(wl.run())
     fence()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * steps)]
-    power = PowerSampler() if world == 1 else None  # (one card per box here; with several ranks each would need its own card's node)
+    power = PowerSampler(wl.Xd.device.index)  # every rank samples its own card; rank 0's goes into the line
     if power:
         power.start()
     t0 = time.perf_counter()
