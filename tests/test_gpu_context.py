@@ -743,3 +743,46 @@ def test_g11_replayed_through_host_pointer_entry_points_only():
     for p in allocs:
         ok(h.bark_dev_free(ctx, p))
     h.bark_ctx_destroy(ctx)
+
+
+def test_host_pointer_entry_points_refuse_what_they_cannot_do(env):
+    """bark_dev_alloc / bark_ctx_upload / bark_ctx_download / bark_tree_swap_eval_host_pair (include/bark_hip.h): status codes, not
+    crashes, for null pointers, a zero-byte allocation and a tree pair with more than 64 leaves (where the reference's own
+    subtract-then-add chain through bark_lowrank_update_hip is the route); a staged round trip of 1 byte, 64 KiB (the pinned
+    page) and 1 MiB (pageable) returns the bytes it was given."""
+    import ctypes as C
+
+    L = env.lib
+    lib, ctx = L.lib(), L.ctx()
+    p = C.c_void_p()
+    assert lib.bark_dev_alloc(ctx, 0, C.byref(p)) == L.BARK_ERR_ARG
+    assert lib.bark_dev_alloc(ctx, 16, None) == L.BARK_ERR_ARG
+    assert lib.bark_ctx_upload(ctx, None, None, 8, None) == L.BARK_ERR_ARG
+    assert lib.bark_ctx_download(ctx, None, None, 8, None) == L.BARK_ERR_ARG
+    for nbytes in (1, 64 * 1024, 1 << 20):
+        src = np.random.default_rng(nbytes).integers(0, 256, size=nbytes, dtype=np.uint8)
+        back = np.zeros_like(src)
+        assert lib.bark_dev_alloc(ctx, nbytes, C.byref(p)) == 0
+        assert lib.bark_ctx_upload(ctx, p, src.ctypes.data, nbytes, L.stream_ptr()) == 0
+        src_copy = src.copy()
+        src[:] = 0  # the host buffer may be reused as soon as the call returns
+        assert lib.bark_ctx_download(ctx, back.ctypes.data, p, nbytes, L.stream_ptr()) == 0
+        assert np.array_equal(back, src_copy)
+        assert lib.bark_dev_free(ctx, p) == 0
+    # a pair of complete depth-6 trees: 64 + 64 leaves > 64
+    syn = env.syn
+    N, d = 256, 4
+    X = np.random.default_rng(1).uniform(size=(N, d))
+    ft = np.full(d, 2, dtype=np.int64)
+    big = syn.full_binary_forests(1, 2, d, 6, np.random.default_rng(3), node_limit=128)[0]  # (2, 128): 64 leaves per tree
+    Xd = L.to_device(X)
+    yd = L.to_device(np.zeros(N))
+    K = L.to_device(np.eye(N))
+    ws = env.torch.empty(int(lib.bark_tree_swap_workspace_bytes(N, 64)), dtype=env.torch.uint8, device=Xd.device)
+    scal, r_out = np.zeros(2), np.zeros(1, dtype=np.int64)
+    pair = np.ascontiguousarray(big)
+    rc = lib.bark_tree_swap_eval_host_pair(ctx, L.ptr(K), N, pair.ctypes.data, pair.shape[1], ft.ctypes.data, d, L.ptr(Xd), 0.1, L.ptr(yd),
+                                           scal.ctypes.data, r_out.ctypes.data, L.ptr(ws), ws.numel(), L.stream_ptr())
+    assert rc == L.BARK_ERR_ARG and b"64" in lib.bark_last_error()
+    assert lib.bark_tree_swap_eval_host_pair(ctx, L.ptr(K), N, None, pair.shape[1], ft.ctypes.data, d, L.ptr(Xd), 0.1, L.ptr(yd),
+                                             scal.ctypes.data, r_out.ctypes.data, L.ptr(ws), ws.numel(), L.stream_ptr()) == L.BARK_ERR_ARG
