@@ -32,9 +32,11 @@ import ctypes
 import hashlib
 import json
 import os
+import shutil
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -59,6 +61,10 @@ def parse(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=3, help="forest samples timed on the host oracle (0 = skip)")
     ap.add_argument("--chunk", type=int, default=0, help="forests factorised concurrently (0 = fit HBM)")
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary per-config measurements")
+    ap.add_argument("--live-traffic", action=argparse.BooleanOptionalAction, default=True,
+                    help="N = 1, launcher path only: after the worker has finished, the GPU-free parent runs the two rocprofv3 --pmc "
+                         "passes (FETCH_SIZE, WRITE_SIZE) on one c3 sweep as child processes and puts the measured HBM bytes per step "
+                         "into roofline.traffic (otherwise: the committed profile of this build, if any)")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU-only check of the launcher / rendezvous / gather / timing protocol (gloo, no GPU work)")
     ap.add_argument("--require-rccl", action=argparse.BooleanOptionalAction, default=None,
@@ -83,10 +89,17 @@ def launch(args) -> int:
         raise SystemExit("--gpus must be >= 1")
     port = _free_port()
     procs = []
+    live = n == 1 and args.live_traffic and not args.selftest_launcher and shutil.which("rocprofv3") is not None
+    line_file = None
+    if live:  # rank 0 hands its JSON line to this process instead of printing it: see live_traffic()
+        fd, line_file = tempfile.mkstemp(prefix="bark_bench_line_", suffix=".json")
+        os.close(fd)
     for r in range(n):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BARK_BENCH_WORKER="1")
+        if line_file:
+            env["BARK_BENCH_LINE_FILE"] = line_file
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this host
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
@@ -107,7 +120,75 @@ def launch(args) -> int:
         for p in procs:
             if p.poll() is None:
                 p.kill()
+    if line_file:
+        try:
+            text = open(line_file).read().strip()
+        finally:
+            os.unlink(line_file)
+        if text:
+            if rc == 0:
+                text = live_traffic(text)
+            print(text, flush=True)
     return rc
+
+
+def live_traffic(line: str) -> str:
+    """roofline.traffic measured in THIS run: the worker process has exited, this (parent) process has never touched the GPU, so
+    it may start the profiler: two `rocprofv3 --pmc` passes (FETCH_SIZE, then WRITE_SIZE: they do not fit one pass on gfx950;
+    counters only, no trace domains, the interpreter directly after `--`) over one warm-up + one c3 sweep of
+    tools/profile_mll.py, event joins (BARK_NO_DEVICE_WAIT: counter passes serialise dispatches).  HBM bytes per step =
+    2 x FETCH_SIZE + WRITE_SIZE over the sweep's kernels (KiB as reported; FETCH doubled as MI355X_MICROARCH.md prescribes for
+    16 B/lane streaming reads on gfx950), per launch sequence.  Any failure leaves the line as the worker wrote it."""
+    import csv
+    import glob
+    import re
+
+    try:
+        res = json.loads(line)
+        cfg = res["config"]
+        N, B = int(cfg["N"]), int(cfg["forests_per_gpu"])
+        env = dict(os.environ, BARK_NO_DEVICE_WAIT="1", PYTHONPATH=ROOT, TMPDIR="/tmp")
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "BARK_BENCH_WORKER", "BARK_BENCH_LINE_FILE"):
+            env.pop(k, None)
+        sweep = ("diag_kernel", "row_kernel", "solve_kernel", "panel_split_kernel", "panel_reduce_kernel")
+        calls, totals = 2, {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = tempfile.mkdtemp(prefix="bark_pmc_%s_" % counter)
+            try:
+                subprocess.run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "t", "--", sys.executable,
+                                os.path.join(ROOT, "tools", "profile_mll.py"), str(N), str(B), str(calls - 1)],
+                               env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+                kib, launches = 0.0, 0
+                for f in glob.glob(os.path.join(out, "**", "*counter_collection*.csv"), recursive=True):
+                    for row in csv.DictReader(open(f)):
+                        m = re.search(r"(\w+_kernel)", row.get("Kernel_Name", ""))
+                        if row.get("Counter_Name") == counter and m and m.group(1) in sweep:
+                            kib += float(row["Counter_Value"])
+                            launches += 1
+                if launches == 0:
+                    raise RuntimeError("no %s rows for the sweep's kernels" % counter)
+                totals[counter] = kib * 1024.0 / calls
+            finally:
+                shutil.rmtree(out, ignore_errors=True)
+        res["roofline"]["traffic"] = 2.0 * totals["FETCH_SIZE"] + totals["WRITE_SIZE"]
+        res["roofline"]["traffic_source"] = {
+            "measured_in_this_run": True, "fetch_bytes_per_step_raw": totals["FETCH_SIZE"], "write_bytes_per_step": totals["WRITE_SIZE"],
+            "command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> --output-format csv -- python3 tools/profile_mll.py %d %d 1 (two passes, "
+                       "started by the GPU-free launcher after the timed worker exited; FETCH doubled on gfx950)" % (N, B),
+            "csrc_digest": csrc_digest()}
+        return json.dumps(res)
+    except Exception as exc:  # the committed profile's figure (or null) stays in the line
+        try:
+            res = json.loads(line)
+            src = res["roofline"].get("traffic_source")
+            note = "live PMC passes failed (%s)" % (repr(exc)[:200])
+            if isinstance(src, dict):
+                src["live_attempt"] = note
+            else:
+                res["roofline"]["traffic_source"] = "%s; %s" % (src, note)
+            return json.dumps(res)
+        except Exception:
+            return line
 
 
 # ---------------------------------------------------------------------------------------------
@@ -710,7 +791,12 @@ def worker(args) -> int:
 
     if world == 1:
         extras(args, wl, result, mll_host)
-    print(json.dumps(result), flush=True)
+    out_file = os.environ.get("BARK_BENCH_LINE_FILE")
+    if out_file:  # the launcher adds the live HBM counters and prints the line (live_traffic)
+        with open(out_file, "w") as f:
+            f.write(json.dumps(result))
+    else:
+        print(json.dumps(result), flush=True)
     return 0
 
 
