@@ -1307,22 +1307,46 @@ __global__ __launch_bounds__(THREADS, 2) void row_kernel(Mats p, int j, int kdon
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
     int b, t;
-    if (syrk == 2) {  // the square tiles first (XCD-aware map over n_right tiles), then one SYRK workgroup per matrix: launch_rows
-        const int first_diag = (int)xcd_grid(n_right, p.Bc);  // a multiple of 8: workgroup id % 8 == b % 8 in the tail as well
+    int rb, cb;
+    if (syrk == 4) {
+        // PAIR launch (plain schedule, lock-step chunks: Sweep::step_paired): block rows j and j+1 over the SAME K range (k < kdone),
+        // n_tiles square tiles per matrix — (j, j+1), then (j, c), (j+1, c) next to each other for every column block c >= j+2, so
+        // that the two tiles that stream the B panel of column block c run side by side on one XCD and the second finds it in L2
+        // — and after all of them the SYRK workgroups of the partial diagonal tiles (j+1, j+1) and, if there is one, (j+2, j+2).
+        const int first_diag = (int)xcd_grid(n_tiles, p.Bc), per = NXCD * ((p.Bc + NXCD - 1) / NXCD);
         if ((int)blockIdx.x >= first_diag) {
-            b = (int)blockIdx.x - first_diag;
-            t = n_right;
+            const int local = (int)blockIdx.x - first_diag, which = local / per;
+            b = local - which * per;
             if (b >= p.Bc) return;
-        } else if (!xcd_map(blockIdx.x, n_right, p.Bc, b, t)) {
+            rb = cb = j + 1 + which;
+        } else {
+            if (!xcd_map(blockIdx.x, n_tiles, p.Bc, b, t)) return;
+            if (t == 0) {
+                rb = j;
+                cb = j + 1;
+            } else {
+                rb = j + ((t - 1) & 1);
+                cb = j + 2 + ((t - 1) >> 1);
+            }
+        }
+    } else {
+        if (syrk == 2) {  // the square tiles first (XCD-aware map over n_right tiles), then one SYRK workgroup per matrix: launch_rows
+            const int first_diag = (int)xcd_grid(n_right, p.Bc);  // a multiple of 8: workgroup id % 8 == b % 8 in the tail as well
+            if ((int)blockIdx.x >= first_diag) {
+                b = (int)blockIdx.x - first_diag;
+                t = n_right;
+                if (b >= p.Bc) return;
+            } else if (!xcd_map(blockIdx.x, n_right, p.Bc, b, t)) {
+                return;
+            }
+        } else if (!xcd_map(blockIdx.x, n_tiles, p.Bc, b, t)) {
             return;
         }
-    } else if (!xcd_map(blockIdx.x, n_tiles, p.Bc, b, t)) {
-        return;
+        rb = t < n_right ? j : j + 1;
+        cb = t < n_right ? j + 1 + t : j + 1;
     }
     const Lane q = lane_of(tid);
     double *Ab = p.A + (size_t)b * p.bstride;
-    const int rb = t < n_right ? j : j + 1;
-    const int cb = t < n_right ? j + 1 + t : j + 1;
     if (syrk && rb == cb) {  // workgroup-uniform: the partial diagonal tile
         const int wsel = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
         double *tile = Ab + (size_t)rb * NB * p.ld + (size_t)cb * NB;
@@ -1880,6 +1904,9 @@ constexpr int PLAIN_CHUNK_MULTIPLE = BARK_PLAIN_CHUNK_MULTIPLE;  // chunks of a 
 #ifndef BARK_PIPE_SYRK_MODE
 #define BARK_PIPE_SYRK_MODE 2  // pipelined schedule's row launches: 1 = SYRK workgroup in its matrix's run of tiles, 2 = after all square tiles
 #endif
+#ifndef BARK_PLAIN_PAIRS
+#define BARK_PLAIN_PAIRS 1  // lock-step chunks of the plain schedule: two block rows per row launch (Sweep::step_paired)
+#endif
 #ifndef BARK_PLAIN_SYRK_MODE
 #define BARK_PLAIN_SYRK_MODE 2  // 0: square diagonal tile; 2: SYRK workgroups after all square tiles (launch_rows)
 #endif
@@ -2019,6 +2046,7 @@ struct Sweep {
     bark_ctx *res = nullptr;
     int nrb = 0, ncb = 0;
     bool fused = false, splitk = false, pipelined = false;
+    bool paired = false;  // plain schedule with two block rows per row launch (step_paired)
     // chain-bound chunks (few matrices): diag_kernel(j) itself waits, at its end, for the row launch solve(j) depends on
     // (device-side progress counter) instead of an event wait on the caller's stream; see diag_kernel
     bool dev_wait = false;
@@ -2107,6 +2135,74 @@ struct Sweep {
         BARK_LAUNCH_CHECK();
         // executed flops: with syrk the partial diagonal tile (present when n_tiles > n_right) takes 36 of 64 sub-block products
         panel_flops += 2.0 * NB * NB * (double)(kdone * NB) * ((double)n_right + (n_tiles > n_right ? (syrk ? 36.0 / 64.0 : 1.0) : 0.0)) * (double)p.Bc;
+        return BARK_OK;
+    }
+
+    // rows j and j+1 over k < j in one launch (row_kernel, syrk == 4); j + 1 < nrb
+    int launch_row_pair(hipStream_t st, int j) {
+        const int nA = ncb - j - 1, nB = nA - 1, n_sq = nA + nB, n_syrk = 1 + ((j + 2 < nrb) ? 1 : 0);
+        const unsigned grid = xcd_grid(n_sq, p.Bc) + (unsigned)(n_syrk * NXCD * ((p.Bc + NXCD - 1) / NXCD));
+        const dim3 g(grid), blk(THREADS);
+        if (!fused)
+            hipLaunchKernelGGL(row_kernel<0>, g, blk, GEMM_LDS, st, p, j, j, nA, n_sq, 4);
+        else if (rep == REP_BITS)
+            hipLaunchKernelGGL(row_kernel<1 + REP_BITS>, g, blk, GEMM_LDS, st, p, j, j, nA, n_sq, 4);
+        else if (rep == REP_BYTES7)
+            hipLaunchKernelGGL(row_kernel<1 + REP_BYTES7>, g, blk, GEMM_LDS, st, p, j, j, nA, n_sq, 4);
+        else
+            hipLaunchKernelGGL(row_kernel<1 + REP_BYTES8>, g, blk, GEMM_LDS, st, p, j, j, nA, n_sq, 4);
+        BARK_LAUNCH_CHECK();
+        panel_flops += 2.0 * NB * NB * (double)(j * NB) * ((double)n_sq + n_syrk * 36.0 / 64.0) * (double)p.Bc;
+        return BARK_OK;
+    }
+
+    // ---- paired plain schedule (lock-step chunks: a multiple of the CU count, not split-K, not pipelined) -----------------------
+    // Two block rows per row launch.  Every tile of block row j streams the B panel of its column block from HBM (a block row's
+    // tiles share only their A panel, through L2): 197 of the sweep's 222 GB of fetches, ~96 W per TB/s on a chip that runs this
+    // sweep at its power cap (profiles/r04/headline_power_wall.txt).  With block rows j and j+1 in ONE launch over the same K
+    // range k < j, the tiles (j, c) and (j+1, c) run side by side and share that panel.  Block row j is then complete
+    // (diag(j) with the two block rows its partial diagonal tile lacks, plain solve(j)); block row j+1 lacks k = j, which
+    // its consumers apply as the pipelined schedule does: diag_kernel(j+1) with one block row and the G block, solve_kernel<1>.
+    //   even j:  [diag(j) || rows(j, j+1)] -> solve<0>(j)          odd j:  diag(j) -> solve<1>(j)
+    // A last unpaired block row (nrb odd) has no tiles to the right unless there are candidate columns: a plain single launch.
+    int step_paired(int j) {
+        hipStream_t s = main, ps = panel;
+        const int bc = p.Bc, n_right = ncb - j - 1;
+        const bool even = (j & 1) == 0, pair = even && j + 1 < nrb;
+        int r;
+        const bool has_rows = even && (pair || n_right > 0) && (j >= 1 || fused);
+        if (has_rows) {
+            BARK_HIP_CHECK(hipEventRecord(res->events[6 * j], s));
+            if ((r = after(ps, res->events[6 * j]))) return r;
+        }
+        // blocks the stored P[j,j] lacks: it came from block row j-1's part of a pair launch (k < j-2 if j-1 is the second row of
+        // its pair, k < j-1 if it is the first)
+        const int nkb = j == 0 ? 0 : (even ? 2 : 1);
+        const bool deferred = !even;  // T'[j,.] lacks k = j-1
+        if ((r = launch_diag(j, nkb, deferred && n_right > 0, -2, j + 1))) return r;
+        if (has_rows) {
+            if (timed) panel_marks.push_back(ev.size());
+            if ((r = mark_on(ps))) return r;
+            if (pair) {
+                if ((r = launch_row_pair(ps, j))) return r;
+            } else if ((r = launch_rows(ps, j, j, n_right, n_right, 0))) {  // (j + 1 == nrb: candidate columns only, no diagonal tile)
+                return r;
+            }
+            if ((r = mark_on(ps))) return r;
+            if ((r = join(6 * j + 1))) return r;
+        }
+        if (n_right > 0) {
+            if (timed) solve_marks.push_back(ev.size());
+            if ((r = mark_on(s))) return r;
+            const dim3 g(xcd_grid(n_right, bc)), blk(THREADS);
+            if (deferred)
+                hipLaunchKernelGGL(solve_kernel<1>, g, blk, GEMM_LDS, s, p, j, n_right);
+            else
+                hipLaunchKernelGGL(solve_kernel<0>, g, blk, GEMM_LDS, s, p, j, n_right);
+            BARK_LAUNCH_CHECK();
+            if ((r = mark_on(s))) return r;
+            solve_flops += ((deferred ? 32.0 : 0.0) + 18.0) / 32.0 * 2.0 * NB * NB * (double)NB * (double)n_right * (double)bc;
+        }
         return BARK_OK;
     }
 
@@ -2264,6 +2360,7 @@ struct Sweep {
     // the critical path of step j remain diag(j) || the rank-128 slab of block row j-1, the reduce and the solve.
     int step(int j) {
         if (pipelined) return step_pipelined(j);
+        if (paired) return step_paired(j);
         hipStream_t s = main, ps = panel;
         const int bc = p.Bc;
         const int n_right = ncb - j - 1;
@@ -2707,6 +2804,7 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
             if ((rc = sw.launch_one_block(y, mll_out + c0, ctx->fault, (flags & BARK_MLL_INCLUDE_2PI) ? 1 : 0))) return rc;
             continue;
         }
+        sw.paired = BARK_PLAIN_PAIRS && !sw.pipelined && !splitk && nrb >= PLAIN_MIN_NRB && bc % PLAIN_CHUNK_MULTIPLE == 0 && sw.panel != sw.main;
         sw.dev_wait = dev_wait_ok && (splitk || sw.pipelined) && bc <= DEVWAIT_MAX_BC;
         // gate kernels in place of the event record that releases the row streams: measured (one process per variant,
         // gates | end-of-diag wait only | events, ms): pipelined N = 4096 x 8 4.44 | 4.59 | 4.64, N = 8192 x 2 8.18 | 8.35 |
