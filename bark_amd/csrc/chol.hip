@@ -361,140 +361,140 @@ __device__ __forceinline__ double recip_pos(double d) {
 template <int K>
 __device__ __forceinline__ double row_bcast_f64(double v) {
     constexpr int ctrl = 0x150 + K;
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xF, 0xF, false);
+    // every lane is written (row_mask = bank_mask = 0xF): mov_dpp leaves the old value undefined, update_dpp(0, ...) costs a
+    // v_mov of the zero per half in front of every broadcast (20 of a block4's ~120 instructions)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
 
-// v of lane (g', c) for g' = 0..3, in every lane of column c (lane = 16 g + c): gfx950's row swaps — v_permlane32_swap leaves
-// rows {0,1,0,1} | {2,3,2,3} of the wave, v_permlane16_swap then row 0 | 1 (2 | 3) in all four — six VALU instructions per
-// double instead of eight ds_bpermute through the LDS crossbar, which the other three waves' MFMA operand reads keep busy
-// (factor16 ran 6.3 K cycles in the first sub-block steps and 8.2 K in the last ones).
-__device__ __forceinline__ void gather_rows(double v, double &r0, double &r1, double &r2, double &r3) {
-    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-    const auto l32 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    const auto h32 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    const auto l01 = __builtin_amdgcn_permlane16_swap(l32[0], l32[0], false, false);
-    const auto h01 = __builtin_amdgcn_permlane16_swap(h32[0], h32[0], false, false);
-    const auto l23 = __builtin_amdgcn_permlane16_swap(l32[1], l32[1], false, false);
-    const auto h23 = __builtin_amdgcn_permlane16_swap(h32[1], h32[1], false, false);
-    r0 = __hiloint2double((int)h01[0], (int)l01[0]);
-    r1 = __hiloint2double((int)h01[1], (int)l01[1]);
-    r2 = __hiloint2double((int)h23[0], (int)l23[0]);
-    r3 = __hiloint2double((int)h23[1], (int)l23[1]);
-}
-
-// Four elimination steps of factor16 at once (pivots K0 = 4Q .. K0+3) on [D | I]; lane (g, c) holds rows g + 4v of
-// column c in e[v] / f[v].  The four pivot rows of block Q are register Q of the four lane groups, so
-//   * their entries at this lane's column cross lane groups once per BLOCK (8 ds_bpermute, issued first) instead of
-//     once per pivot,
-//   * the 4 x 4 diagonal block comes by v_readlane (wave-uniform) and every lane repeats its small LDL factorisation
-//     (4 reciprocals on the dependent chain instead of 16 pivot-to-pivot round trips),
-//   * the multipliers of the lane's own rows are read from the pivot COLUMNS (the trailing block is symmetric) by DPP
-//     row broadcasts and pushed through the block's unit-lower factor, then applied as one rank-4 update.
-// The per-element operation order is that of four single-pivot steps.
+// Four elimination steps of factor16 at once (pivots K0 = 4Q .. K0+3) on [D | I]; lane (g, c) holds rows g + 4v of column c in
+// e[v] / f[v] — which is the D layout of the 16x16x4 MFMA, so the cross-lane work of the block goes through the matrix pipe.
+// (The wave is bound by the ISSUE of its instructions — ~8 cycles per fp64 VALU operation, 4 per 32-bit one — not by the
+// pivot-to-pivot latency: round 3's form, with lane swaps, a per-row multiplier recurrence and two FMA chains per row
+// register, was ~930 instructions and 6.0 K cycles per 16 pivots.)
+//   * the four pivot rows (register Q of the four lane groups) reach every lane group by ONE product with a 0/1 selector
+//     (exact), instead of six lane-swap instructions and as many copies per double;
+//   * the 4 x 4 diagonal block is eliminated inside those rows: the pivot and the multipliers of step k are row k's entries
+//     at the block's columns (DPP row broadcasts); the four reciprocals stay on the dependent chain;
+//   * the rank-4 update of ALL rows below — D -= M A, I -= M S with M[i][k] = A_k[i] / d_k, the pivot rows' own entries at
+//     column i: the trailing block is symmetric and only its upper triangle is ever read — is one MFMA each.  M is zeroed
+//     for the rows of this block and the finished ones.
+// The pivots, hence log|D|, are bit-identical to the single-pivot order; entries below them differ from it in the last bits
+// (multipliers taken from the pivot row instead of the pivot column).
+// Out: piv[Q][k] the pivots (1.0 where one was not positive: flagged in badbits, the sweep continues finite), dsel[Q] the
+// pivot of this lane's row g + 4Q.
 template <int Q>
-__device__ __forceinline__ void block4(double (&e)[4], double (&f)[4], double (&piv)[4][4], int c, int g, int base_index,
-                                       int &bad) {
+__device__ __forceinline__ void block4(f64x4 &e, f64x4 &f, double (&piv)[4][4], double (&dsel)[4], int &badbits, int c, int g,
+                                       double gsel) {
     constexpr int K0 = 4 * Q;
-    double A0, A1, A2, A3, S0, S1, S2, S3;
-    gather_rows(e[Q], A0, A1, A2, A3);  // D[K0 + j][c]
-    gather_rows(f[Q], S0, S1, S2, S3);  // I[K0 + j][c]
-    const double P00 = readlane_f64(e[Q], 0 * 16 + K0 + 0), P01 = readlane_f64(e[Q], 0 * 16 + K0 + 1),
-                 P02 = readlane_f64(e[Q], 0 * 16 + K0 + 2), P03 = readlane_f64(e[Q], 0 * 16 + K0 + 3),
-                 P11 = readlane_f64(e[Q], 1 * 16 + K0 + 1), P12 = readlane_f64(e[Q], 1 * 16 + K0 + 2),
-                 P13 = readlane_f64(e[Q], 1 * 16 + K0 + 3), P22 = readlane_f64(e[Q], 2 * 16 + K0 + 2),
-                 P23 = readlane_f64(e[Q], 2 * 16 + K0 + 3), P33 = readlane_f64(e[Q], 3 * 16 + K0 + 3);
-    auto pivot = [&](double d, int k) {  // not positive definite / NaN: flag once, continue finite
-        if (!(d > 0.0)) {
-            if (!bad) bad = base_index + K0 + k + 1;
-            d = 1.0;
-        }
-        return recip_pos(d);
+    const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
+    const f64x4 Ar = __builtin_amdgcn_mfma_f64_16x16x4f64(gsel, e[Q], zero, 0, 0, 0);  // Ar[k] = D[K0 + k][c]
+    double S0, S1, S2, S3;
+    if constexpr (Q == 0) {  // still the identity
+        S0 = c == 0 ? 1.0 : 0.0;
+        S1 = c == 1 ? 1.0 : 0.0;
+        S2 = c == 2 ? 1.0 : 0.0;
+        S3 = c == 3 ? 1.0 : 0.0;
+    } else {
+        const f64x4 Sr = __builtin_amdgcn_mfma_f64_16x16x4f64(gsel, f[Q], zero, 0, 0, 0);  // I[K0 + k][c]
+        S0 = Sr[0];
+        S1 = Sr[1];
+        S2 = Sr[2];
+        S3 = Sr[3];
+    }
+    double A0 = Ar[0], A1 = Ar[1], A2 = Ar[2], A3 = Ar[3];
+    auto pivot = [&](double d, int k) {  // d is wave-uniform
+        const bool ok = d > 0.0;  // false for NaN too
+        badbits |= ok ? 0 : 1 << (K0 + k);
+        return ok ? d : 1.0;
     };
-    const double rd0 = pivot(P00, 0);
-    const double l10 = P01 * rd0, l20 = P02 * rd0, l30 = P03 * rd0;
-    const double d1 = fma(-l10, P01, P11), t12 = fma(-l10, P02, P12), t13 = fma(-l10, P03, P13);
-    const double rd1 = pivot(d1, 1);
-    const double l21 = t12 * rd1, l31 = t13 * rd1;
-    const double d2 = fma(-l21, t12, fma(-l20, P02, P22)), t23 = fma(-l21, t13, fma(-l20, P03, P23));
-    const double rd2 = pivot(d2, 2);
-    const double l32 = t23 * rd2;
-    const double d3 = fma(-l32, t23, fma(-l31, t13, fma(-l30, P03, P33)));
-    const double rd3 = pivot(d3, 3);
-    piv[Q][0] = P00;  // the frozen pivots, wave-uniform (factor16's tail needs no cross-lane traffic for them)
-    piv[Q][1] = d1;
-    piv[Q][2] = d2;
-    piv[Q][3] = d3;
-    // the block's own rows after its four steps, at this lane's column
+    const double p0 = pivot(row_bcast_f64<K0 + 0>(A0), 0);
+    const double rd0 = recip_pos(p0);
+    const double l10 = row_bcast_f64<K0 + 1>(A0) * rd0, l20 = row_bcast_f64<K0 + 2>(A0) * rd0, l30 = row_bcast_f64<K0 + 3>(A0) * rd0;
     A1 = fma(-l10, A0, A1);
+    const double p1 = pivot(row_bcast_f64<K0 + 1>(A1), 1);
+    const double rd1 = recip_pos(p1);
+    const double l21 = row_bcast_f64<K0 + 2>(A1) * rd1, l31 = row_bcast_f64<K0 + 3>(A1) * rd1;
     A2 = fma(-l21, A1, fma(-l20, A0, A2));
+    const double p2 = pivot(row_bcast_f64<K0 + 2>(A2), 2);
+    const double rd2 = recip_pos(p2);
+    const double l32 = row_bcast_f64<K0 + 3>(A2) * rd2;
     A3 = fma(-l32, A2, fma(-l31, A1, fma(-l30, A0, A3)));
+    const double p3 = pivot(row_bcast_f64<K0 + 3>(A3), 3);
+    piv[Q][0] = p0;
+    piv[Q][1] = p1;
+    piv[Q][2] = p2;
+    piv[Q][3] = p3;
     S1 = fma(-l10, S0, S1);
     S2 = fma(-l21, S1, fma(-l20, S0, S2));
     S3 = fma(-l32, S2, fma(-l31, S1, fma(-l30, S0, S3)));
-    // rows below the block: multipliers from the pivot columns, then the rank-4 update
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        if (v > Q) {
-            const double a0 = row_bcast_f64<K0 + 0>(e[v]);
-            double a1 = row_bcast_f64<K0 + 1>(e[v]), a2 = row_bcast_f64<K0 + 2>(e[v]), a3 = row_bcast_f64<K0 + 3>(e[v]);
-            const double m0 = a0 * rd0;
-            a1 = fma(-m0, P01, a1);
-            const double m1 = a1 * rd1;
-            a2 = fma(-m1, t12, fma(-m0, P02, a2));
-            const double m2 = a2 * rd2;
-            a3 = fma(-m2, t23, fma(-m1, t13, fma(-m0, P03, a3)));
-            const double m3 = a3 * rd3;
-            e[v] = fma(-m3, A3, fma(-m2, A2, fma(-m1, A1, fma(-m0, A0, e[v]))));
-            f[v] = fma(-m3, S3, fma(-m2, S2, fma(-m1, S1, fma(-m0, S0, f[v]))));
-        }
+    // lane group k owns row K0 + k of the block
+    const double X = g == 0 ? A0 : g == 1 ? A1 : g == 2 ? A2 : A3;
+    const double Sx = g == 0 ? S0 : g == 1 ? S1 : g == 2 ? S2 : S3;
+    dsel[Q] = g == 0 ? p0 : g == 1 ? p1 : g == 2 ? p2 : p3;
+    if constexpr (Q + 1 < 4) {
+        const double rd3 = recip_pos(p3);
+        const double R = g == 0 ? rd0 : g == 1 ? rd1 : g == 2 ? rd2 : rd3;
+        // A operand of lane (i = c, k = g): -M[i][k]
+        const double mneg = c >= K0 + 4 ? -(X * R) : 0.0;
+        e = __builtin_amdgcn_mfma_f64_16x16x4f64(mneg, X, e, 0, 0, 0);
+        f = __builtin_amdgcn_mfma_f64_16x16x4f64(mneg, Sx, f, 0, 0, 0);
     }
-    // lane group j owns row K0 + j of the block
-    e[Q] = g == 0 ? A0 : g == 1 ? A1 : g == 2 ? A2 : A3;
-    f[Q] = g == 0 ? S0 : g == 1 ? S1 : g == 2 ? S2 : S3;
-    if constexpr (Q + 1 < 4) block4<Q + 1>(e, f, piv, c, g, base_index, bad);
+    e[Q] = X;
+    f[Q] = Sx;
+    if constexpr (Q + 1 < 4) block4<Q + 1>(e, f, piv, dsel, badbits, c, g, gsel);
 }
 
-__device__ __forceinline__ void factor16(double *blk, int lane, int base_index, double &logsum, int &bad) {
+// One wave eliminates the 16x16 diagonal sub-block `blk` and overwrites it with W = U_kk^-1; `pacc` collects the pivots
+// for log|D|: lane l keeps the product of the four pivots of block (l & 3) of the sub-block number ((l >> 2) & 7), and
+// pivots_logsum turns the lot into the sum of logs ONCE per tile (the double-precision log is ~100 fp64 instructions,
+// ~800 cycles: per sub-block it was an eighth of the chain).
+__device__ __forceinline__ void factor16(double *blk, int lane, int base_index, double &pacc, int &bad) {
     const int c = lane & 15, g = lane >> 4;
-    double e[4], f[4];
+    f64x4 e, f;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         e[v] = blk[(g + 4 * v) * SB + c];
         f[v] = (g + 4 * v == c) ? 1.0 : 0.0;
     }
-    double piv[4][4];  // piv[q][i] = pivot of row 4q + i, identical in every lane
-    block4<0>(e, f, piv, c, g, base_index, bad);
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (!(piv[qq][i] > 0.0)) piv[qq][i] = 1.0;  // flagged above; keep the rest finite
-    // log|D| = sum of the 16 log pivots: lane l takes the product of block (l & 3)'s four pivots — one log per lane —
-    // and the four values meet by two quad-permute DPP adds (a log per elimination step, or a 16-lane ds_bpermute
-    // reduction, costs more than the rest of this tail)
+    double piv[4][4], dsel[4];
+    int badbits = 0;
+    block4<0>(e, f, piv, dsel, badbits, c, g, g == (c >> 2) ? 1.0 : 0.0);
+    const int first = __builtin_ffs(badbits);  // 1 + index of the first pivot that was not positive; 0: none
+    bad = (bad == 0 && first != 0) ? base_index + first : bad;
     {
         const int sel = lane & 3;
         const double p0 = (piv[0][0] * piv[0][1]) * (piv[0][2] * piv[0][3]), p1 = (piv[1][0] * piv[1][1]) * (piv[1][2] * piv[1][3]),
                      p2 = (piv[2][0] * piv[2][1]) * (piv[2][2] * piv[2][3]), p3 = (piv[3][0] * piv[3][1]) * (piv[3][2] * piv[3][3]);
-        double lg = log(sel == 0 ? p0 : sel == 1 ? p1 : sel == 2 ? p2 : p3);
-        lg += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(lg), 0xB1, 0xF, 0xF, false),   // quad_perm [1,0,3,2]
-                               __builtin_amdgcn_update_dpp(0, __double2loint(lg), 0xB1, 0xF, 0xF, false));
-        lg += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(lg), 0x4E, 0xF, 0xF, false),   // quad_perm [2,3,0,1]
-                               __builtin_amdgcn_update_dpp(0, __double2loint(lg), 0x4E, 0xF, 0xF, false));
-        logsum += 0.5 * lg;
+        const double ps = sel == 0 ? p0 : sel == 1 ? p1 : sel == 2 ? p2 : p3;
+        pacc = ((lane >> 2) & 7) == (base_index >> 4) ? ps : pacc;
     }
-    // row r of the right half is (L~^-1)[r][:]; U^-T = diag(1/sqrt d) L~^-1, so W[c][r] = f * rsqrt(d_r), r = g + 4v:
-    // pivot g of block v.  1/sqrt by v_rsq_f64 + two Newton steps (full double accuracy; IEEE sqrt + divide is ~4x longer)
+    // row r of the right half is (L~^-1)[r][:]; U^-T = diag(1/sqrt d) L~^-1, so W[c][r] = f * rsqrt(d_r), r = g + 4v.
+    // 1/sqrt by v_rsq_f64 + two Newton steps (full double accuracy; IEEE sqrt + divide is ~4x longer)
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        const double dr = g == 0 ? piv[v][0] : g == 1 ? piv[v][1] : g == 2 ? piv[v][2] : piv[v][3];
+        const double dr = dsel[v];
         double rs = __builtin_amdgcn_rsq(dr);
         rs = rs * fma(-0.5 * dr * rs, rs, 1.5);
         rs = rs * fma(-0.5 * dr * rs, rs, 1.5);
         blk[c * SB + (g + 4 * v)] = f[v] * rs;
     }
+}
+
+// sum over the tile's sub-blocks of 0.5 log(product of the 16 pivots), from factor16's per-lane products (pacc starts at 1.0;
+// every lane of the wave): one log per lane, the four blocks of a sub-block meet by two quad-permute DPP adds, the eight
+// sub-blocks are added in order.
+__device__ __forceinline__ double pivots_logsum(double pacc) {
+    double lg = log(pacc);
+    lg += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(lg), 0xB1, 0xF, 0xF, false),   // quad_perm [1,0,3,2]
+                           __builtin_amdgcn_update_dpp(0, __double2loint(lg), 0xB1, 0xF, 0xF, false));
+    lg += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(lg), 0x4E, 0xF, 0xF, false),   // quad_perm [2,3,0,1]
+                           __builtin_amdgcn_update_dpp(0, __double2loint(lg), 0x4E, 0xF, 0xF, false));
+    double s = 0.0;
+#pragma unroll
+    for (int kb = 0; kb < NSB; ++kb) s += 0.5 * readlane_f64(lg, 4 * kb);
+    return s;
 }
 
 // Rank-128 update of the diagonal tile, upper block triangle only: D = P - U[j-1,j]' U[j-1,j] for the 36 sub-blocks
@@ -611,7 +611,7 @@ __device__ __forceinline__ void diag_update(const double *__restrict__ tile, lon
 // Wave 0 stores the sub-block (0,0) first and eliminates it while its other loads — and the other waves' — are still in
 // flight (the tile load and factor16(0) used to be 4 K + 6 K cycles one after the other, with three waves idle in the second).
 template <int W>
-__device__ __forceinline__ void diag_copy(const double *__restrict__ tile, long ld, double *S, int lane, int lr, int lk, double &logsum,
+__device__ __forceinline__ void diag_copy(const double *__restrict__ tile, long ld, double *S, int lane, int lr, int lk, double &pacc,
                                           int &bad) {
     using T = UpperBlocks<W>;
     double pre[9][4];
@@ -627,7 +627,7 @@ __device__ __forceinline__ void diag_copy(const double *__restrict__ tile, long 
         if (W == 0 && i == 0) {  // UpperBlocks<0>: sub-block (0,0)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            factor16(blk, lane, 0, logsum, bad);
+            factor16(blk, lane, 0, pacc, bad);
         }
     }
 }
@@ -817,19 +817,20 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
         for (int e = tid; e < p.nW * NB; e += THREADS) codes[e] = lb[e];
         __syncthreads();
     }
-    double logsum = 0.0;
+    double logsum = 0.0;  // sum of log(pivot) / 2 ... (wave 0; pivots_logsum in the last sub-block step)
+    double pacc = 1.0;    // ... from factor16's pivot products
     int bad = 0;
     const bool copy_only = !ONE && nkb == 0;  // workgroup-uniform
     if (copy_only) {
         const int wsel = __builtin_amdgcn_readfirstlane(wave);
         if (wsel == 0)
-            diag_copy<0>(tile, p.ld, S, lane, q.lr, q.lk, logsum, bad);
+            diag_copy<0>(tile, p.ld, S, lane, q.lr, q.lk, pacc, bad);
         else if (wsel == 1)
-            diag_copy<1>(tile, p.ld, S, lane, q.lr, q.lk, logsum, bad);
+            diag_copy<1>(tile, p.ld, S, lane, q.lr, q.lk, pacc, bad);
         else if (wsel == 2)
-            diag_copy<2>(tile, p.ld, S, lane, q.lr, q.lk, logsum, bad);
+            diag_copy<2>(tile, p.ld, S, lane, q.lr, q.lk, pacc, bad);
         else
-            diag_copy<3>(tile, p.ld, S, lane, q.lr, q.lk, logsum, bad);
+            diag_copy<3>(tile, p.ld, S, lane, q.lr, q.lk, pacc, bad);
     } else {
         // D = P - sum_k U[k,j]'U[k,j] on the upper block triangle (the product stages alias S: the update's last barrier
         // precedes the writes of S)
@@ -847,7 +848,7 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
     __syncthreads();
 
     // --- blocked Cholesky D = U'U and X = U^-1, software-pipelined over the four waves ------------------------------
-    // The serial part is the eight 16x16 eliminations (factor16, one wave, ~5.4 K cycles each).  Wave 0 runs that
+    // The serial part is the eight 16x16 eliminations (factor16, one wave, ~3.8 K cycles each; 6.0 K before round 4's MFMA form).  Wave 0 runs that
     // chain: in step kb it updates only the NEXT diagonal sub-block with row kb and factors it, while waves 1-3 do the
     // rest of step kb's trailing update (C) and the column kb of the inverse — so neither waits for the other:
     //   top of step kb (all waves)  (B) U[kb,cb] = W_kk' D[kb,cb], cb > kb                       | barrier
@@ -867,7 +868,7 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
                          wave_u == 1 ? (ONE ? 6 : 5) : wave_u == 2 ? 4 : wave_u == 3 ? 3 : -1, (ONE && wave_u == 3) ? 5 : -1};
     f64x4 pend[3];  // column kb of X (transposed, see x_entry) for the owned rows, stored at the start of the next step
     if (!copy_only) {
-        if (wave_u == 0) factor16(S + blk_off(0, 0), lane, 0, logsum, bad);
+        if (wave_u == 0) factor16(S + blk_off(0, 0), lane, 0, pacc, bad);
         __syncthreads();
     }
     // one-block-row matrices of fewer than 113 points: the sub-blocks beyond the last live one are identity padding — their
@@ -899,9 +900,11 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
                 for (int v = 0; v < 4; ++v) dst[(lk + 4 * v) * SB + lr] -= u[v];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                factor16(dst, lane, (kb + 1) * SB, logsum, bad);
-            } else if (!ONE) {  // last step: nothing left to eliminate — the one entry of X's row 6
-                pend[0] = x_entry(xw, tw, xrow[0], kb, nsb, S, dblk, lr, lk);
+                factor16(dst, lane, (kb + 1) * SB, pacc, bad);
+            } else {  // last step: nothing left to eliminate — the one entry of X's row 6, and the logs of all the pivots (this
+                      // wave used to wait ~3 K cycles for the others here)
+                if (!ONE) pend[0] = x_entry(xw, tw, xrow[0], kb, nsb, S, dblk, lr, lk);
+                logsum = pivots_logsum(pacc);
             }
             __syncthreads();
         }

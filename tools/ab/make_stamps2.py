@@ -23,9 +23,9 @@ def once(old, new):
 once("namespace {\n\ntypedef double f64x4", "__device__ unsigned long long g_stamps[64];\n#define STAMP(i) do { if (!ONE && blockIdx.x == 0 && threadIdx.x == 0) g_stamps[i] = __builtin_readcyclecounter(); } while (0)\nnamespace {\n\ntypedef double f64x4")
 once("    const int info_in = (tid == 0 && !one) ? p.info[b] : 0;\n", "    const int info_in = (tid == 0 && !one) ? p.info[b] : 0;\n    STAMP(0);\n")
 once("    __syncthreads();\n\n    // --- blocked Cholesky D = U'U and X = U^-1", "    __syncthreads();\n    STAMP(1);\n\n    // --- blocked Cholesky D = U'U and X = U^-1")
-once("        if (wave_u == 0) factor16(S + blk_off(0, 0), lane, 0, logsum, bad);\n        __syncthreads();\n    }\n", "        if (wave_u == 0) factor16(S + blk_off(0, 0), lane, 0, logsum, bad);\n        __syncthreads();\n    }\n    STAMP(2);\n")
+once("        if (wave_u == 0) factor16(S + blk_off(0, 0), lane, 0, pacc, bad);\n        __syncthreads();\n    }\n", "        if (wave_u == 0) factor16(S + blk_off(0, 0), lane, 0, pacc, bad);\n        __syncthreads();\n    }\n    STAMP(2);\n")
 once("            double *dblk = S + blk_off(kb, kb);  // W_kk\n            phase_b(kb, dblk);\n            __syncthreads();\n            if (kb + 1 < nsb) {\n", "            double *dblk = S + blk_off(kb, kb);  // W_kk\n            STAMP(8 + kb);\n            phase_b(kb, dblk);\n            __syncthreads();\n            STAMP(16 + kb);\n            if (kb + 1 < nsb) {\n")
-once("                factor16(dst, lane, (kb + 1) * SB, logsum, bad);\n", "                factor16(dst, lane, (kb + 1) * SB, logsum, bad);\n                STAMP(24 + kb);\n")
+once("                factor16(dst, lane, (kb + 1) * SB, pacc, bad);\n", "                factor16(dst, lane, (kb + 1) * SB, pacc, bad);\n                STAMP(24 + kb);\n")
 once("    {  // last column of X", "    STAMP(3);\n    {  // last column of X")
 once("    // --- W_j out, sub-block by sub-block", "    STAMP(4);\n    // --- W_j out, sub-block by sub-block")
 once("    if (want_g)  // workgroup-uniform", "    STAMP(5);\n    if (want_g)  // workgroup-uniform")
