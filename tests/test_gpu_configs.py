@@ -76,6 +76,40 @@ def test_c3_b256_plain_schedule():
     assert np.isfinite(got).all()
 
 
+def test_c3_b256_all_samples_against_vendor_cholesky():
+    """The headline shape again, ALL 256 samples against a solver that shares nothing with the sweep (the oracle takes ~5 s per
+    sample, hence three of them in the test above): the device Gram matrices (bit-exact against the oracle in
+    test_gpu_parity.py) through torch.linalg.cholesky, the vendor's batched fp64 factorisation.  A checker, like the oracle:
+    nothing in the product calls it."""
+    import torch
+
+    import bark_amd.fitting as fit
+    import bark_amd.forest as bf
+    from bark_amd import synthetic as syn
+
+    N, B, m = 4096, 256, 50
+    X, y, bounds, ft = syn.unit_cube_problem(N, 8, seed=N)
+    F = syn.sample_prior_forests(B, m, bounds, ft, seed=N)
+    noise = np.random.default_rng(N).uniform(0.05, 0.15, B)
+    Xd = torch.from_numpy(X).cuda()
+    got = fit.batched_mll(F, noise, None, Xd, y, ft, chunk=256, include_scale=False, include_2pi=True)
+    yd = torch.from_numpy(np.asarray(y, dtype=np.float64).reshape(-1)).cuda()
+    eye = torch.eye(N, dtype=torch.float64, device="cuda")
+    ref = np.empty(B)
+    for c0 in range(0, B, 16):
+        K = bf.batched_forest_gram_matrix(F[c0:c0 + 16], Xd, Xd, ft)
+        K += (1e-6 + torch.from_numpy(noise[c0:c0 + 16]).cuda())[:, None, None] * eye
+        try:
+            L = torch.linalg.cholesky(K)
+        except RuntimeError as e:  # a torch build without a batched potrf
+            pytest.skip(f"torch.linalg.cholesky unavailable on this box: {e}")
+        z = torch.linalg.solve_triangular(L, yd.expand(L.shape[0], N)[:, :, None], upper=False)[:, :, 0]
+        logdet = 2.0 * L.diagonal(dim1=1, dim2=2).log().sum(1)
+        ref[c0:c0 + 16] = (0.5 * (-(z * z).sum(1) - logdet - N * np.log(2.0 * np.pi))).cpu().numpy()
+        del K, L, z
+    assert np.allclose(got, ref, rtol=MLL_RTOL, atol=MLL_ATOL), np.abs(got / ref - 1.0).max()
+
+
 def test_n2200_b256_one_chunk_of_256():
     """A second shape of the plain schedule's class (18 block rows >= 16, 256 resident matrices), ragged N, mixed feature
     types, scale included; the chunk = 96 call is the pipelined schedule on the same forests."""
