@@ -1165,6 +1165,32 @@ def extras(args, wl, result, mll_host):
         result["sampler_step"] = sampler_step_probe(args, wl)
         result["fitting_loop_harness"] = fitting_loop_probe()
 
+    # ---- yardstick, not a baseline the metric is quoted against: the vendor's batched fp64 Cholesky (torch.linalg.cholesky ->
+    # rocSOLVER / MAGMA) on 64 of this workload's matrices — the factorisation ALONE (no Gram generation, no solve, no MLL) beside
+    # the sweep's whole evaluation of the same 64 (the `configs` row "c4 per-GPU share").  Nothing in the product calls it.
+    if not args.no_configs and N == 4096:
+        try:
+            import bark_amd.forest as bf
+
+            nb = 64
+            Kv = bf.batched_forest_gram_matrix(wl.forests[:nb], wl.Xd, wl.Xd, wl.ft)
+            Kv += (1e-6 + wl.noise_d[:nb])[:, None, None] * torch.eye(N, dtype=torch.float64, device=wl.Xd.device)
+            torch.linalg.cholesky(Kv)
+            v0, v1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            v0.record()
+            for _ in range(3):
+                torch.linalg.cholesky(Kv)
+            v1.record()
+            torch.cuda.synchronize()
+            v_ms = v0.elapsed_time(v1) / 3
+            result["vendor_cholesky_yardstick"] = {
+                "what": "torch.linalg.cholesky (vendor batched fp64 potrf) on %d N=%d matrices of this workload: factorisation only" % (nb, N),
+                "ms": v_ms, "tflops": nb * N**3 / 3.0 / (v_ms * 1e-3) / 1e12,
+                "backend": str(torch.backends.cuda.preferred_linalg_library())}
+            del Kv
+        except Exception as exc:  # pragma: no cover - a torch build without a batched potrf
+            result["vendor_cholesky_yardstick"] = {"error": repr(exc)}
+
     # ---- informational only: the leaf-space evaluation of the SAME MLLs (R x R system over the leaves instead
     # of the N x N matrix).  It does not do the Gram + Cholesky work the metric counts and is not part of `value`.
     pf = wl.pf
