@@ -687,6 +687,35 @@ def test_not_positive_definite_raises(B):
         B.fit.batched_mll(forest, np.full(4, -0.5), None, X, y, ft, include_scale=False, include_2pi=True)
 
 
+@pytest.mark.parametrize("N,dup,m,eps", [(90, 40, 50, 1e-3), (300, 150, 50, 1e-3), (300, 150, 200, 1e-3), (700, 600, 200, 1e-3),
+                                         (700, 600, 400, 1e-4)])
+def test_not_positive_definite_reports_the_first_bad_pivot(B, N, dup, m, eps):
+    """The index in the error is LAPACK potrf's `info`: the 1-based position of the first pivot that is not positive when the
+    matrix is eliminated in order — also when it lies in a later 4-pivot block of factor16, a later 16 x 16 sub-block of
+    diag_kernel or a later 128-row block step of the sweep (badbits, base_index, j * 128).  K - eps I with one duplicated point:
+    the elimination fails at the duplicate (pivot ~ -2 eps) or earlier, where the forest's rank runs out — positions 40, 56, 150,
+    162 and 390 for these inputs.  The expected index comes from an unblocked numpy elimination of the same matrix and must be a
+    clear failure (|pivot| > 1e-4, six orders above what rounding moves), so it cannot depend on the order of operations."""
+    import re
+
+    X, y, bounds, ft = B.syn.mixed_problem(N, seed=N)
+    X = X.copy()
+    X[dup - 1] = X[0]
+    F = B.syn.sample_prior_forests(1, m, bounds, ft, seed=N)
+    noise = -1e-6 - eps
+    A, want = B.orc.forest_gram_matrix(F[0], X, X, ft) + (1e-6 + noise) * np.eye(N), 0
+    for k in range(N):
+        if not A[k, k] > 0.0:
+            want = k + 1
+            assert A[k, k] < -1e-4, A[k, k]
+            break
+        A[k + 1:, k + 1:] -= np.outer(A[k + 1:, k], A[k, k + 1:]) / A[k, k]
+    assert want > 0
+    with pytest.raises(np.linalg.LinAlgError, match="not positive definite") as exc:
+        B.fit.batched_mll(F, [noise], None, X, y, ft, include_scale=False, include_2pi=True)
+    assert int(re.search(r"pivot (\d+)", str(exc.value)).group(1)) == want, (str(exc.value), want)
+
+
 def test_argument_validation_across_the_api(B):
     """Bad shapes / unsupported options raise Python exceptions (SURVEY §8b error behaviour); nothing aborts."""
     X, y, bounds, ft = B.syn.mixed_problem(90, seed=3)
