@@ -380,8 +380,9 @@ __device__ __forceinline__ double row_bcast_f64(double v) {
 //   * the rank-4 update of ALL rows below — D -= M A, I -= M S with M[i][k] = A_k[i] / d_k, the pivot rows' own entries at
 //     column i: the trailing block is symmetric and only its upper triangle is ever read — is one MFMA each.  M is zeroed
 //     for the rows of this block and the finished ones.
-// The pivots, hence log|D|, are bit-identical to the single-pivot order; entries below them differ from it in the last bits
-// (multipliers taken from the pivot row instead of the pivot column).
+// Inside a block the pivots are formed by the single-pivot order's operations; the rows below it get multipliers taken from the
+// pivot ROW instead of the pivot column and the MFMA's own summation, so the factor agrees with round 3's to rounding (the parity
+// tests' rtol 1e-9 against the oracle is met with the same margin, ~1e-14 relative at N = 4096), not bit for bit.
 // Out: piv[Q][k] the pivots (1.0 where one was not positive: flagged in badbits, the sweep continues finite), dsel[Q] the
 // pivot of this lane's row g + 4Q.
 template <int Q>
