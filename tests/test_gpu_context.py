@@ -563,6 +563,54 @@ def test_pipelined_sweep_of_16_matrices_is_capturable(env):
     assert bool((wl.mll_d == eager).all()) and int(wl.info_d.abs().max().item()) == 0
 
 
+_SERIALISED_SCRIPT = """
+import os, sys, time
+sys.path.insert(0, {root!r})
+import torch, bench
+from bark_amd import _lib
+wl = bench.Workload(1100, 8, 50, 8, seed_base=1100, rank_offset=0)
+wl.run(); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(3):
+    wl.run()
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print("STATE", bench.device_wait_state(_lib.lib()), "INFO", int(wl.info_d.abs().max().item()), "SECONDS", dt)
+print("MLL", wl.mll_d.cpu().numpy().tobytes().hex())
+"""
+
+
+@pytest.mark.parametrize("var", ["HIP_LAUNCH_BLOCKING", "AMD_SERIALIZE_KERNEL", "BARK_NO_DEVICE_WAIT"])
+def test_dispatch_serialising_environments_switch_the_device_wait_off(env, var):
+    """under serialised dispatch every device-side wait would run into its 2 s bound (the row launch a
+    diag_kernel waits for cannot run beside it).  The library reads the environment once: with HIP_LAUNCH_BLOCKING,
+    AMD_SERIALIZE_KERNEL or BARK_NO_DEVICE_WAIT set it uses event joins from the start.  A child process per variable (the
+    switch is process-wide and read at first use): chunk of 8 matrices, 9 block rows — a shape that takes the device-side
+    hand-over otherwise — mechanism reported off, no time-out (info == 0), three calls in well under one wait bound, and the
+    same bits as this process computes with the mechanism on."""
+    import os
+    import subprocess
+    import sys
+
+    import bench
+
+    torch = env.torch
+    wl = bench.Workload(1100, 8, 50, 8, seed_base=1100, rank_offset=0)
+    wl.run()
+    torch.cuda.synchronize()
+    want = wl.mll_d.cpu().numpy().tobytes().hex()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child_env = dict(os.environ)
+    child_env[var] = "3" if var == "AMD_SERIALIZE_KERNEL" else "1"
+    r = subprocess.run([sys.executable, "-c", _SERIALISED_SCRIPT.format(root=root)], capture_output=True, text=True, timeout=600,
+                       env=child_env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    state = [ln for ln in r.stdout.splitlines() if ln.startswith("STATE")][0].split()
+    assert state[1] == "off" and int(state[3]) == 0 and float(state[5]) < 1.5, state
+    got = [ln for ln in r.stdout.splitlines() if ln.startswith("MLL")][0].split()[1]
+    assert got == want
+
+
 def test_device_wait_from_a_side_stream_and_from_two_threads(env):
     """the device-side hand-over had only been driven from the default stream.  Here (a) from a non-default
     caller stream and (b) from two host threads at once, each with its own context and stream: bit-identical to the serial
