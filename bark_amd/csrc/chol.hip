@@ -382,7 +382,7 @@ __device__ __forceinline__ double row_bcast_f64(double v) {
 //     for the rows of this block and the finished ones.
 // Inside a block the pivots are formed by the single-pivot order's operations; the rows below it get multipliers taken from the
 // pivot ROW instead of the pivot column and the MFMA's own summation, so the factor agrees with round 3's to rounding (the parity
-// tests' rtol 1e-9 against the oracle is met with the same margin, ~1e-14 relative at N = 4096), not bit for bit.
+// tests' rtol 1e-9 against the reference's arithmetic is met with the same margin, ~1e-14 relative at N = 4096), not bit for bit.
 // Out: piv[Q][k] the pivots (1.0 where one was not positive: flagged in badbits, the sweep continues finite), dsel[Q] the
 // pivot of this lane's row g + 4Q.
 template <int Q>
