@@ -42,12 +42,23 @@ class MllTiming(ctypes.Structure):
     ]
 
 
-# every exported symbol of include/bark_hip.h: name -> (restype, argtypes)
+class MllPlan(ctypes.Structure):
+    """bark_mll_plan (include/bark_hip.h): which launch schedule bark_mll_batched_hip takes for a shape."""
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "n_chunks", "chunk", "last_chunk", "schedule", "last_schedule", "splitk_layout", "fused_gram", "dev_wait", "dev_gate",
+        "pre_update", "lookahead_steps", "splitk_steps", "nrb", "ncb")]
+
+
+SCHEDULES = ("one_block", "plain", "paired", "pipelined", "splitk", "splitk_lookahead")  # BARK_SCHED_*
+
+
+# every exported symbol of include/*.h: name -> (restype, argtypes)
 SIGNATURES = {
     "bark_version": (ci, []),
     "bark_last_error": (ctypes.c_char_p, []),
     "bark_device_wait": (ci, [ci]),
     "bark_xcd_map_selftest": (ci, [ci, ci]),
+    "bark_mll_plan_query": (ci, [i64, i64, i64, i64, i64, ci, ci, ctypes.POINTER(MllPlan)]),
     "bark_debug_fail_launch": (ctypes.c_long, [ctypes.c_long]),
     "bark_dev_alloc": (ci, [vp, ctypes.c_size_t, ctypes.POINTER(vp)]),
     "bark_dev_free": (ci, [vp, vp]),

@@ -1891,6 +1891,10 @@ constexpr int SPLITK_LAYOUT_MAX_TILES = BARK_SPLITK_LAYOUT_MAX_TILES;
 constexpr int64_t SPLITK_LAYOUT_MAX_WORK = BARK_SPLITK_LAYOUT_MAX_WORK;
 // Build-time tuning constants of the pipelined schedule (numbers only: every on/off alternative that was measured and
 // lost is gone from the sources, with its figures left in the comment next to the code that won).
+#ifndef BARK_PIPE_PLAIN_WORK
+#define BARK_PIPE_PLAIN_WORK 0
+#endif
+constexpr long PIPE_PLAIN_WORK = BARK_PIPE_PLAIN_WORK;  // see plan_chunk / Sweep::plain_until (0: pipelined from block row 0)
 #ifndef BARK_PIPE_MIN_NRB
 #define BARK_PIPE_MIN_NRB 8
 #endif
@@ -1901,7 +1905,11 @@ constexpr int PIPE_MIN_NRB = BARK_PIPE_MIN_NRB;  // fewer block rows: plain sche
 constexpr int PLAIN_CHUNK_MULTIPLE = BARK_PLAIN_CHUNK_MULTIPLE;  // chunks of a multiple of this many matrices (and >= PLAIN_MIN_NRB block rows): plain
 // round 4 (diagonal tile as a SYRK after the square tiles, in both schedules) — plain | pipelined, ms, same box: N = 2200 x 256
 // 18.21 | 18.44, N = 3000 x 256 40.70 | 41.10, N = 4096 x 256 92.45 | 93.05, N = 1536 x 256 (12 block rows) 6.29 | 6.24,
-// N = 1536 x 512 11.97 | 12.24, N = 1100 x 256 3.12 | 3.13: the rule stays at 16 block rows
+// N = 1536 x 512 11.97 | 12.24, N = 1100 x 256 3.12 | 3.13.  The boundary itself — chunks of EXACTLY 16 block rows (N = 1921..2048)
+// take the plain / paired schedule (nrb >= PLAIN_MIN_NRB), 15 block rows and fewer the pipelined one — measured in round 5 with the
+// paired launches, paired | pipelined (-DBARK_PLAIN_MIN_NRB=17), same box: N = 2048 x 256 13.31 | 13.36, N = 1930 x 256 13.26 | 13.27,
+// N = 2048 x 512 26.00 | 26.24 (profiles/r05/nrb16_boundary_ab.txt); parity at that shape: tests/test_gpu_configs.py::
+// test_sixteen_block_rows_b256_is_the_boundary_of_the_paired_schedule
 #ifndef BARK_PLAIN_MIN_NRB
 #define BARK_PLAIN_MIN_NRB 16
 #endif
@@ -2085,6 +2093,17 @@ struct Sweep {
         touch(st);
         BARK_HIP_CHECK(hipStreamWaitEvent(st, e, 0));
         return BARK_OK;
+    }
+    // Everything enqueued on helper stream `st` so far has been ordered in front of what follows on the caller's stream (an event
+    // recorded at its tail is awaited there, directly or through a stream that is joined next): nothing of it is left to rejoin.
+    // Work put on it later touches it again.  With this the closing rejoin_helpers() of a call whose schedule joined by events
+    // finds nothing to do — it used to record and await up to three more events on the caller's stream (5-13 us each on a
+    // chain-bound call, and as many extra edges in a captured graph).
+    void joined(hipStream_t st) {
+        if (!res || st == main) return;
+        if (st == res->helper) touched &= ~1u;
+        if (st == res->helper2) touched &= ~2u;
+        if (st == res->helper3) touched &= ~4u;
     }
     // everything enqueued on the touched helper streams so far precedes what follows on the caller's stream.  Best effort,
     // keeps the thread's error message: it also runs on the way out of a failed call.
@@ -2273,6 +2292,7 @@ struct Sweep {
         if (panel == main) return BARK_OK;
         BARK_HIP_CHECK(hipEventRecord(res->events[slot], panel));
         BARK_HIP_CHECK(hipStreamWaitEvent(main, res->events[slot], 0));
+        joined(panel);
         return BARK_OK;
     }
 
@@ -2393,6 +2413,7 @@ struct Sweep {
                 if ((r = after(ps, res->events[6 * j]))) return r;
             }
         }
+        hipStream_t bulk_next_stream = nullptr;
         if (bulk_next) {
             const int j2 = j + 1, S2 = split_factor(j2, j2 - 1, la_slots(j2));
             // bulk-bound steps alternate between two streams, so that a bulk does not queue behind the last workgroups
@@ -2400,6 +2421,7 @@ struct Sweep {
             // critical-path-bound steps two resident bulks would only take slots from the critical path
             // (N = 4096, B = 8: 5.04 -> 5.26 ms)
             hipStream_t ls = ((j2 & 1) && la_slots(j2) == LA_SLOTS) ? la_stream2 : la_stream;
+            bulk_next_stream = ls;
             if (dev_gate) {
                 if ((r = gate(ls, j + 1))) return r;
             } else {
@@ -2416,6 +2438,10 @@ struct Sweep {
             if (la) {  // the last block row of the K range; the bulk [0, j-1) was launched after solve(j-2)
                 if ((r = launch_split(ps, j, j - 1, j, 1, S, S + 1))) return r;
                 if ((r = after(ps, res->events[6 * j + 2]))) return r;  // the bulk slabs of step j
+                {  // the stream of bulk(j) is covered by the join of ps below — unless bulk(j + 1) has just gone onto it as well
+                    hipStream_t lsj = ((j & 1) && la_slots(j) == LA_SLOTS) ? la_stream2 : la_stream;
+                    if (!wait_in_diag && lsj != bulk_next_stream) joined(lsj);
+                }
                 if ((r = launch_reduce(ps, j, S + 1))) return r;
             } else if (S > 1) {
                 if ((r = launch_split(ps, j, 0, j, S, 0, S))) return r;
@@ -2470,7 +2496,15 @@ struct Sweep {
     //   caller's stream  diag(j) -> [wait bulk(j)] solve(j) -> diag(j+1) -> ...
     //   helper streams   bulk(j+2) after solve(j)
     // Every bulk launch is awaited on the caller's stream at its own step, so the pattern stays fork/join (capturable).
-    int kdone(int j) const { return j > 0 ? j - 1 : 0; }
+    // plain_until (round 5): the first block steps of a pipelined chunk keep the WHOLE K range in their row launch
+    // (kdone(j) = j for j < plain_until: launched after solve(j-1), beside diag(j), plain solve) — while the row work of a step
+    // is short, the step is bound by the chain diag -> solve -> diag, and deferring the last block row makes exactly that chain
+    // longer (diag_kernel with two block rows and the G block, a K = 256 solve: 2.8 x the plain solve's flops) for an overlap
+    // nothing needs yet.  From plain_until on the launches go out two steps ahead as described above; the consumers read how
+    // many block rows a stored tile lacks from kdone(), so the two forms mix freely.  See plan_chunk for the rule.
+    int plain_until = 0;
+    int next_bulk = 0;  // first block row whose row launch has not been enqueued yet
+    int kdone(int j) const { return j < plain_until ? j : (j > 0 ? j - 1 : 0); }
     int tiles_of(int j) const { return (ncb - j - 1) + ((j + 1 < nrb) ? 1 : 0); }
     // a K = 0 launch only generates A (fused sweeps); with a materialised A there is nothing to do
     bool has_bulk(int j) const { return j < nrb_steps && tiles_of(j) > 0 && (kdone(j) > 0 || fused); }
@@ -2478,8 +2512,9 @@ struct Sweep {
         if (!has_bulk(j)) return BARK_OK;
         hipStream_t st = (j & 1) ? la_stream : panel;  // one bulk stream only: B = 256 at N = 4096 94 -> 100 ms
         int r;
-        if (dev_gate && j >= 2) {  // called right after solve(j-2): diag_kernel(j-1), next on `main`, publishes j when it starts
-            if ((r = gate(st, j))) return r;
+        // called right after solve(done), done = kdone(j) - 1: diag_kernel(done + 1), next on `main`, publishes done + 2 when it starts
+        if (dev_gate && kdone(j) >= 1) {
+            if ((r = gate(st, kdone(j) + 1))) return r;
         } else {
             BARK_HIP_CHECK(hipEventRecord(res->events[6 * j + 3], main));
             if ((r = after(st, res->events[6 * j + 3]))) return r;
@@ -2520,8 +2555,9 @@ struct Sweep {
                 BARK_HIP_CHECK(hipEventRecord(res->events[5], main));
                 if ((r = after(panel, res->events[5])) || (r = after(la_stream, res->events[5]))) return r;
             }
-            if ((r = launch_bulk(0))) return r;
-            if ((r = launch_bulk(1))) return r;
+            next_bulk = 0;
+            for (; next_bulk < nrb_steps && kdone(next_bulk) == 0; ++next_bulk)  // block row 0, and 1 unless it is a plain step
+                if ((r = launch_bulk(next_bulk))) return r;
         }
         // the stored P_jj comes from the row launch of block row j-1: block rows kdone(j-1) .. j-1 are still to apply
         const bool deferred = j > kdone(j);
@@ -2530,7 +2566,10 @@ struct Sweep {
         if ((r = launch_diag(j, j > 0 ? j - kdone(j - 1) : 0, deferred && n_right > 0, wait_in_diag ? (j & 1) : (dev_wait ? -1 : -2),
                              j + 1)))
             return r;
-        if (has_bulk(j) && !wait_in_diag) BARK_HIP_CHECK(hipStreamWaitEvent(main, res->events[6 * j + 2], 0));
+        if (has_bulk(j) && !wait_in_diag) {
+            BARK_HIP_CHECK(hipStreamWaitEvent(main, res->events[6 * j + 2], 0));
+            joined((j & 1) ? la_stream : panel);  // bulk(j)'s stream; bulk(j + 2) touches it again
+        }
         if (n_right > 0) {
             if (timed) solve_marks.push_back(ev.size());
             if ((r = mark_on(main))) return r;
@@ -2553,7 +2592,10 @@ struct Sweep {
             if ((r = mark_on(main))) return r;
             solve_flops += ((deferred ? 32.0 : 0.0) + 18.0) / 32.0 * 2.0 * NB * NB * (double)NB * (double)n_right * (double)bc;
         }
-        return launch_bulk(j + 2);
+        // the row launches that only waited for solve(j): block row j+1 if it is a plain step, j+2 (or j+1, j+2 at the change-over)
+        for (; next_bulk < nrb_steps && kdone(next_bulk) <= j + 1; ++next_bulk)
+            if ((r = launch_bulk(next_bulk))) return r;
+        return BARK_OK;
     }
 
     // fill *t from the recorded events (synchronises); [t_begin, t_end] bracket the whole call on `caller`
@@ -2590,6 +2632,81 @@ struct Sweep {
         return BARK_OK;
     }
 };
+
+// Which schedule a chunk of bc resident matrices takes — the ONE place that decides it: bark_mll_batched_hip configures its
+// Sweep from this, and bark_mll_plan_query reports it (DESIGN.md section 4 has the table for the BASELINE configs; a -m gpu
+// test asserts it, so that a tuning constant cannot silently move the headline shape onto another schedule).
+//   sw: splitk / fused / nrb / ncb / nrb_steps / la_stream set; p.Bc is set here (lookahead() reads the chunk size).
+struct ChunkPlan {
+    bool one_block, pipelined, paired, dev_wait, dev_gate, pre_update;
+    int lookahead_steps, splitk_steps;
+    int plain_until;  // pipelined schedule: block steps [0, plain_until) keep their whole K range in the row launch (Sweep::kdone)
+};
+ChunkPlan plan_chunk(Sweep &sw, int64_t bc, int64_t C, bool timing, bool dev_wait_ok, bool two_streams) {
+    ChunkPlan c{};
+    const int nrb = sw.nrb;
+    const bool splitk = sw.splitk;
+    sw.plain_until = 0;
+    // Pipelined schedule: pays whenever the plain schedule leaves ragged rounds of workgroups (measured at N = 4096:
+    // B = 40 +15 %, 64 +7 %, 96 +9 %, 160 +5 %, 192 +4 %; N = 8192, B = 32 +7 %; N = 2048, B = 128..192 +5 %).  When Bc
+    // is a multiple of the 256 CUs every round of the plain schedule is full or exactly half full; the two then tie at
+    // N = 4096 (93.6 | 93.7 ms at B = 256), the plain one wins beyond (B = 512: 186.6 | 188.6; N = 8192, B = 256:
+    // 696 | 711) and the pipelined one up to 16 block rows (N = 2048: 14.1 | 13.8, N = 1024: 2.65 | 2.56).  Fewer than 8
+    // block rows: no difference measured (N = 512..896), plain.
+    const bool pipeline_ok = !splitk && nrb >= PIPE_MIN_NRB;
+    c.pipelined = pipeline_ok && ((bc % PLAIN_CHUNK_MULTIPLE) != 0 || nrb < PLAIN_MIN_NRB);
+    c.one_block = nrb == 1 && sw.fused && C == 0 && !timing;  // N <= 128: leaf walk + ONE launch per chunk (OneBlock)
+    sw.p.Bc = (int)bc;  // lookahead() / split_factor() read the chunk size
+    if (c.one_block) {
+        c.pipelined = false;
+        return c;
+    }
+    c.paired = BARK_PLAIN_PAIRS && !c.pipelined && !splitk && nrb >= PLAIN_MIN_NRB && bc % PLAIN_CHUNK_MULTIPLE == 0 && two_streams;
+    c.dev_wait = dev_wait_ok && (splitk || c.pipelined) && bc <= DEVWAIT_MAX_BC;
+    // gate kernels in place of the event record that releases the row streams: measured (one process per variant,
+    // gates | end-of-diag wait only | events, ms): pipelined N = 4096 x 8 4.44 | 4.59 | 4.64, N = 8192 x 2 8.18 | 8.35 |
+    // 8.48; split-K layout N = 4096 x 1 2.19 | 2.14 | 2.22, N = 1024 x 1 0.575 | 0.520 | 0.534 — pipelined only
+    // ... split-K layout: only for sweeps with look-ahead steps (N = 6900 x 1 5.02 -> 4.59 with gates; without look-ahead
+    // they cost: N = 4096 x 1 2.04 -> 2.28, N = 2048 x 4 1.09 -> 1.21)
+    c.dev_gate = c.dev_wait && c.pipelined;
+    if (!c.pipelined && !c.paired) {
+        for (int jj = 1; jj < nrb; ++jj) {
+            const bool la = sw.lookahead(jj);
+            c.lookahead_steps += la ? 1 : 0;
+            c.splitk_steps += (la || sw.split_factor(jj, jj) > 1) ? 1 : 0;
+        }
+        if (c.dev_wait && c.lookahead_steps > 0) c.dev_gate = true;
+    } else if (c.pipelined) {
+        // Sweep::plain_until: the pipelined form from the first block step on whose row launch holds PIPE_PLAIN_WORK
+        // tile x block-row products (4.2 MFLOP each: 2400 of them are ~150 us of the whole chip at the row kernel's rate, about
+        // what the deferred chain diag(two block rows + G) -> K = 256 solve costs beside resident row workgroups)
+        sw.plain_until = 0;
+        if (PIPE_PLAIN_WORK > 0) {
+            int jj = 1;
+            for (; jj < nrb; ++jj)
+                if ((long)sw.tiles_of(jj) * bc * (jj - 1) >= PIPE_PLAIN_WORK) break;
+            sw.plain_until = jj;
+        }
+        c.plain_until = sw.plain_until;
+        for (int jj = 0; jj < nrb; ++jj) {
+            const int k = sw.kdone(jj), nt = sw.tiles_of(jj);
+            if (sw.has_bulk(jj) && k >= 2 && nt * (int)bc < SPLITK_SLOTS / 2 && (2 * PIPE_BULK_SLOTS + nt * (int)bc) / (2 * nt * (int)bc) >= 2)
+                ++c.splitk_steps;
+        }
+    }
+    // split-K layout only: same box, this | inside diag_kernel, ms — N = 4096 x 1 2.035 | 2.130, N = 1024 x 1 0.492 | 0.514,
+    // N = 2048 x 4 1.082 | 1.125; in the pipelined schedule the extra launch queues for slots behind the resident row
+    // workgroups like every kernel of the chain does (N = 4096 x 8 4.77 | 4.46, x 16 7.61 | 7.11, N = 16384 x 1 27.2 | 25.4)
+    c.pre_update = splitk && bc <= DEVWAIT_MAX_BC;
+    return c;
+}
+int plan_code(const ChunkPlan &c, bool splitk) {
+    if (c.one_block) return BARK_SCHED_ONE_BLOCK;
+    if (c.paired) return BARK_SCHED_PAIRED;
+    if (c.pipelined) return BARK_SCHED_PIPELINED;
+    if (splitk) return c.lookahead_steps > 0 ? BARK_SCHED_SPLITK_LOOKAHEAD : BARK_SCHED_SPLITK;
+    return BARK_SCHED_PLAIN;
+}
 
 }  // namespace
 }  // namespace bark
@@ -2632,6 +2749,42 @@ int bark_device_wait(int on) {
 size_t bark_mll_workspace_bytes(int64_t N, int64_t C, int64_t m, int64_t Bc) {
     if (N < 1 || C < 0 || m < 1 || Bc < 1) return 0;
     return make_layout(N, C, m, Bc).total;
+}
+
+// Which schedule bark_mll_batched_hip takes for (N, C, m, B, Bc): plan_chunk's decisions for the first and the last chunk.
+// No GPU needed (the device-side hand-over is reported as the process switch stands, outside stream capture).
+int bark_mll_plan_query(int64_t N, int64_t C, int64_t m, int64_t B, int64_t Bc, int leaf_words, int timing, bark_mll_plan *out) {
+    error_buffer()[0] = 0;
+    if (!out || N < 1 || C < 0 || m < 1 || B < 1 || Bc < 1 || leaf_words < 1)
+        return fail(BARK_ERR_ARG, "bark_mll_plan_query: bad argument");
+    if (Bc > B) Bc = B;
+    if (Bc > 65535) Bc = 65535;
+    const Layout L = make_layout(N, C, m, Bc);
+    Sweep sw;
+    sw.nrb = sw.nrb_steps = (int)(L.npad / NB);
+    sw.ncb = (int)(L.ncols / NB);
+    sw.splitk = L.splitk;
+    sw.fused = !L.splitk && C == 0 && (size_t)2 * leaf_words * NB * sizeof(uint32_t) <= GEMM_LDS;
+    sw.la_stream = sw.la_stream2 = reinterpret_cast<hipStream_t>(&sw);  // non-null: look-ahead possible (never dereferenced)
+    const bool dw = device_wait_enabled().load();
+    const int64_t last = B % Bc ? B % Bc : Bc;
+    const ChunkPlan lastp = plan_chunk(sw, last, C, timing != 0, dw, true);
+    const ChunkPlan first = plan_chunk(sw, Bc, C, timing != 0, dw, true);
+    out->n_chunks = (int32_t)((B + Bc - 1) / Bc);
+    out->chunk = (int32_t)Bc;
+    out->last_chunk = (int32_t)last;
+    out->schedule = plan_code(first, L.splitk);
+    out->last_schedule = plan_code(lastp, L.splitk);
+    out->splitk_layout = L.splitk ? 1 : 0;
+    out->fused_gram = sw.fused ? 1 : 0;
+    out->dev_wait = first.dev_wait ? 1 : 0;
+    out->dev_gate = first.dev_gate ? 1 : 0;
+    out->pre_update = first.pre_update ? 1 : 0;
+    out->lookahead_steps = first.lookahead_steps;
+    out->splitk_steps = first.splitk_steps;
+    out->nrb = sw.nrb;
+    out->ncb = sw.ncb;
+    return BARK_OK;
 }
 
 int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info *info, const double *X, int64_t N, int64_t d,
@@ -2686,13 +2839,6 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
     sw.ncb = ncb;
     sw.fused = fused;
     sw.splitk = splitk;
-    // Pipelined schedule: pays whenever the plain schedule leaves ragged rounds of workgroups (measured at N = 4096:
-    // B = 40 +15 %, 64 +7 %, 96 +9 %, 160 +5 %, 192 +4 %; N = 8192, B = 32 +7 %; N = 2048, B = 128..192 +5 %).  When Bc
-    // is a multiple of the 256 CUs every round of the plain schedule is full or exactly half full; the two then tie at
-    // N = 4096 (93.6 | 93.7 ms at B = 256), the plain one wins beyond (B = 512: 186.6 | 188.6; N = 8192, B = 256:
-    // 696 | 711) and the pipelined one up to 16 block rows (N = 2048: 14.1 | 13.8, N = 1024: 2.65 | 2.56).  Fewer than 8
-    // block rows: no difference measured (N = 512..896), plain.
-    const bool pipeline_ok = !splitk && nrb >= PIPE_MIN_NRB;  // decided per chunk below
     sw.rep = rep;
     sw.slabs = slabs;
     sw.timed = timing != nullptr;
@@ -2791,8 +2937,9 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
     auto chunks = [&]() -> int {
     for (int64_t c0 = 0; c0 < B; c0 += Bc) {  // chunks of Bc resident matrices, one after the other
         const int64_t bc = (B - c0 < Bc) ? (B - c0) : Bc;
-        sw.pipelined = pipeline_ok && ((bc % PLAIN_CHUNK_MULTIPLE) != 0 || nrb < PLAIN_MIN_NRB);
-        if (nrb == 1 && fused && C == 0 && !timing) {  // N <= 128: leaf walk + ONE launch per chunk (OneBlock)
+        const ChunkPlan plan = plan_chunk(sw, bc, C, timing != nullptr, dev_wait_ok, sw.panel != sw.main);  // (sets sw.p.Bc)
+        sw.pipelined = plan.pipelined;
+        if (plan.one_block) {  // N <= 128: leaf walk + ONE launch per chunk (OneBlock)
             Mats &p1 = sw.p;
             bark_pack_info sub = *info;
             sub.B = bc;
@@ -2808,22 +2955,10 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
             if ((rc = sw.launch_one_block(y, mll_out + c0, ctx->fault, (flags & BARK_MLL_INCLUDE_2PI) ? 1 : 0))) return rc;
             continue;
         }
-        sw.paired = BARK_PLAIN_PAIRS && !sw.pipelined && !splitk && nrb >= PLAIN_MIN_NRB && bc % PLAIN_CHUNK_MULTIPLE == 0 && sw.panel != sw.main;
-        sw.dev_wait = dev_wait_ok && (splitk || sw.pipelined) && bc <= DEVWAIT_MAX_BC;
-        // gate kernels in place of the event record that releases the row streams: measured (one process per variant,
-        // gates | end-of-diag wait only | events, ms): pipelined N = 4096 x 8 4.44 | 4.59 | 4.64, N = 8192 x 2 8.18 | 8.35 |
-        // 8.48; split-K layout N = 4096 x 1 2.19 | 2.14 | 2.22, N = 1024 x 1 0.575 | 0.520 | 0.534 — pipelined only
-        // ... split-K layout: only for sweeps with look-ahead steps (N = 6900 x 1 5.02 -> 4.59 with gates; without look-ahead
-        // they cost: N = 4096 x 1 2.04 -> 2.28, N = 2048 x 4 1.09 -> 1.21)
-        sw.dev_gate = sw.dev_wait && sw.pipelined;
-        if (sw.dev_wait && !sw.pipelined) {
-            sw.p.Bc = (int)bc;  // lookahead() reads the chunk size
-            for (int jj = 2; jj < nrb && !sw.dev_gate; ++jj) sw.dev_gate = sw.lookahead(jj);
-        }
-        // split-K layout only: same box, this | inside diag_kernel, ms — N = 4096 x 1 2.035 | 2.130, N = 1024 x 1 0.492 | 0.514,
-        // N = 2048 x 4 1.082 | 1.125; in the pipelined schedule the extra launch queues for slots behind the resident row
-        // workgroups like every kernel of the chain does (N = 4096 x 8 4.77 | 4.46, x 16 7.61 | 7.11, N = 16384 x 1 27.2 | 25.4)
-        sw.pre_update = splitk && bc <= DEVWAIT_MAX_BC;
+        sw.paired = plan.paired;
+        sw.dev_wait = plan.dev_wait;
+        sw.dev_gate = plan.dev_gate;
+        sw.pre_update = plan.pre_update;
         sw.finished = false;
         sw.fin_mll = (C == 0 && !timing) ? mll_out + c0 : nullptr;
         sw.fin_fault = ctx->fault;
@@ -2841,10 +2976,16 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
     };
     rc = chunks();
     if (rc) {  // an error return from the middle of a chunk: helper streams may be forked (under capture: unjoined)
+        // a gate kernel of a helper stream may be waiting for a diag_kernel that will now never be launched: raise the sticky
+        // time-out word first, so that it gives up at once instead of holding the rejoin for its 2 s bound (best effort)
+        if (sw.dev_gate && sw.p.sync) {
+            hipLaunchKernelGGL(sync_publish_kernel, dim3(1), dim3(1), 0, caller, sw.p.sync, 2, 1);
+            (void)hipGetLastError();
+        }
         sw.rejoin_helpers();
         return rc;
     }
-    sw.rejoin_helpers();  // (event-join schedules have joined every launch already: nothing is left touched to wait for)
+    sw.rejoin_helpers();  // whatever is still marked touched (Sweep::joined clears a stream's mark when an event join covers it)
     const size_t t_end = sw.ev.size();
     if ((rc = sw.mark_on(caller))) return rc;
     if (timing) return sw.report(timing, t_begin, t_end, caller);
@@ -2981,7 +3122,7 @@ static int leafspace_run(bark_ctx *ctx, const void *packed, const bark_pack_info
         const char *packed_c = static_cast<const char *>(packed) + (size_t)c0 * m * info->stride * 16;
         p.info = info_out + c0;
         p.Bc = (int)bc;
-        sw.pipelined = !g.L.splitk && nrb >= PIPE_MIN_NRB && ((bc % PLAIN_CHUNK_MULTIPLE) != 0 || nrb < PLAIN_MIN_NRB);  // as the dense entry
+        sw.pipelined = !g.L.splitk && nrb >= PIPE_MIN_NRB && ((bc % PLAIN_CHUNK_MULTIPLE) != 0 || nrb < PLAIN_MIN_NRB);  // plan_chunk's rule
         if ((rc = walk_one_hot(packed_c, &sub, X, N, d, (int)g.W, codes, ctx->fault, caller))) return rc;
         rc = leafspace_prepare(codes, (int)g.W, (int)g.npad, planes, (int)g.R, (int)g.Rpad, noise + c0,
                                use_scale ? scale + c0 : nullptr, (int)m, (int)bc, p.A, p.ld, p.bstride, y, (int)N, p.yz,

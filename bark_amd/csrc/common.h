@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/bark_hip.h"
+#include "../../include/bark_hip_testing.h"
 
 namespace bark {
 
@@ -23,7 +24,7 @@ int fail(int code, const char *fmt, ...);
                                 __FILE__, __LINE__);                                               \
     } while (0)
 
-// Status of the launch just made: hipGetLastError(), or — test hook bark_debug_fail_launch(k) — an injected failure of the
+// Status of the launch just made: hipGetLastError(), or — test hook bark_debug_fail_launch(k), $BARK_TEST_HOOKS processes only — an injected failure of the
 // k-th checked launch of the process (the kernel itself was enqueued; what is exercised is the error return path).
 hipError_t launch_status();
 #define BARK_LAUNCH_CHECK() BARK_HIP_CHECK(::bark::launch_status())
@@ -48,6 +49,8 @@ struct bark_ctx {
     int32_t *fault_host = nullptr;            // pinned mirror for bark_ctx_status
     char *stage_host = nullptr;               // pinned staging page of the host-pointer entry points (bark_ctx_upload, ..._host_pair)
     char *stage_dev = nullptr;                // its device twin
+    hipEvent_t stage_event = nullptr;         // recorded behind the last staged asynchronous copy, on the stream it went to ...
+    bool stage_busy = false;                  // ... and not yet waited for: the next staged call does, before it touches the page
 };
 
 namespace bark {

@@ -5,6 +5,7 @@
 // explicitly.  The only process-wide state left is the thread-local last-error buffer and the once-per-device
 // dynamic-LDS attributes of the kernels (std::call_once).
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -12,12 +13,19 @@
 namespace bark {
 
 namespace {
+// Launch-failure injection (include/bark_hip_testing.h) exists only in processes started with $BARK_TEST_HOOKS set: read once,
+// when the library is loaded.  Without it launch_status() is hipGetLastError() plus one test of a constant.
+const bool g_test_hooks = [] {
+    const char *v = std::getenv("BARK_TEST_HOOKS");
+    return v && v[0] && !(v[0] == '0' && v[1] == 0);
+}();
 std::atomic<long> g_fail_countdown{0};
 }
 
 hipError_t launch_status() {
     const hipError_t e = hipGetLastError();
-    if (g_fail_countdown.load(std::memory_order_relaxed) > 0 && g_fail_countdown.fetch_sub(1) == 1) return hipErrorLaunchFailure;
+    if (g_test_hooks && g_fail_countdown.load(std::memory_order_relaxed) > 0 && g_fail_countdown.fetch_sub(1) == 1)
+        return hipErrorLaunchFailure;
     return e;
 }
 
@@ -75,9 +83,13 @@ using namespace bark;
 
 extern "C" {
 
-// Test hook: the k-th launch from now on whose status the library checks reports hipErrorLaunchFailure (k <= 0: off).
-// Process-wide; returns the previous countdown.
-long bark_debug_fail_launch(long k) { return g_fail_countdown.exchange(k > 0 ? k : 0); }
+// Test hook (include/bark_hip_testing.h): the k-th launch from now on whose status the library checks reports
+// hipErrorLaunchFailure (k <= 0: off).  Process-wide; returns the previous countdown — or -1, and does nothing, in a process
+// that was not started with $BARK_TEST_HOOKS set.
+long bark_debug_fail_launch(long k) {
+    if (!g_test_hooks) return -1;
+    return g_fail_countdown.exchange(k > 0 ? k : 0);
+}
 
 int bark_ctx_create(int device, bark_ctx **out) {
     error_buffer()[0] = 0;
@@ -136,6 +148,7 @@ void bark_ctx_destroy(bark_ctx *ctx) {
     if (ctx->fault_host) (void)hipHostFree(ctx->fault_host);
     if (ctx->stage_host) (void)hipHostFree(ctx->stage_host);
     if (ctx->stage_dev) (void)hipFree(ctx->stage_dev);
+    if (ctx->stage_event) (void)hipEventDestroy(ctx->stage_event);
     (void)hipSetDevice(prev);
     delete ctx;
 }
@@ -192,9 +205,23 @@ int bark_ctx_status(bark_ctx *ctx, void *stream_, int32_t *cat_fault_out) {
 // (bark_forest_pack*, bark_mll_batched_hip, bark_lowrank_swap_apply_hip, bark_lowrank_status_hip, bark_ctx_status) already
 // takes plain pointers.  INTEGRATION.md §4 shows the nopython caller.
 // ---------------------------------------------------------------------------------------------------------------
-static int ensure_stage(bark_ctx *ctx) {
+// The staging page (one pinned host page + its device twin per context) is shared by every staged entry point, whatever
+// stream the caller passes: a staged copy records ctx->stage_event behind itself on its stream (stage_release), and the next
+// staged call waits for THAT event before it touches the page (stage_acquire) — not for its own stream, which may be another
+// one (upload on stream A, then upload or a host-pair proposal on stream B used to overwrite the page under A's pending copy).
+static int stage_acquire(bark_ctx *ctx) {
     if (!ctx->stage_host) BARK_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->stage_host), STAGE_BYTES, hipHostMallocDefault));
     if (!ctx->stage_dev) BARK_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->stage_dev), STAGE_BYTES));
+    if (!ctx->stage_event) BARK_HIP_CHECK(hipEventCreateWithFlags(&ctx->stage_event, hipEventDisableTiming));
+    if (ctx->stage_busy) {
+        BARK_HIP_CHECK(hipEventSynchronize(ctx->stage_event));
+        ctx->stage_busy = false;
+    }
+    return BARK_OK;
+}
+static int stage_release(bark_ctx *ctx, hipStream_t s) {  // the page is in use by everything enqueued on s so far
+    BARK_HIP_CHECK(hipEventRecord(ctx->stage_event, s));
+    ctx->stage_busy = true;
     return BARK_OK;
 }
 
@@ -230,11 +257,10 @@ int bark_ctx_upload(bark_ctx *ctx, void *dst_dev, const void *src_host, size_t b
     if (bytes == 0) return BARK_OK;
     hipStream_t s = static_cast<hipStream_t>(stream_);
     if (bytes <= STAGE_BYTES) {
-        if ((rc = ensure_stage(ctx))) return rc;
-        BARK_HIP_CHECK(hipStreamSynchronize(s));  // an earlier staged copy on this stream has left the page
+        if ((rc = stage_acquire(ctx))) return rc;  // an earlier staged copy — on whatever stream — has left the page
         std::memcpy(ctx->stage_host, src_host, bytes);
         BARK_HIP_CHECK(hipMemcpyAsync(dst_dev, ctx->stage_host, bytes, hipMemcpyHostToDevice, s));
-        return BARK_OK;
+        return stage_release(ctx, s);
     }
     BARK_HIP_CHECK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, s));
     BARK_HIP_CHECK(hipStreamSynchronize(s));
@@ -249,8 +275,7 @@ int bark_ctx_download(bark_ctx *ctx, void *dst_host, const void *src_dev, size_t
     if (!dst_host || !src_dev) return fail(BARK_ERR_ARG, "bark_ctx_download: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream_);
     if (bytes > 0 && bytes <= STAGE_BYTES) {
-        if ((rc = ensure_stage(ctx))) return rc;
-        BARK_HIP_CHECK(hipStreamSynchronize(s));  // (an earlier staged upload has left the page)
+        if ((rc = stage_acquire(ctx))) return rc;  // (an earlier staged upload has left the page)
         BARK_HIP_CHECK(hipMemcpyAsync(ctx->stage_host, src_dev, bytes, hipMemcpyDeviceToHost, s));
         BARK_HIP_CHECK(hipStreamSynchronize(s));
         std::memcpy(dst_host, ctx->stage_host, bytes);
@@ -291,15 +316,17 @@ int bark_tree_swap_eval_host_pair(bark_ctx *ctx, const double *K_inv, int64_t N,
     constexpr size_t SCALARS_AT = STAGE_BYTES - 64;
     if ((size_t)info.packed_bytes > SCALARS_AT)
         return fail(BARK_ERR_ARG, "bark_tree_swap_eval_host_pair: packed pair of %lld bytes exceeds the staging page", (long long)info.packed_bytes);
-    if ((rc = ensure_stage(ctx))) return rc;
+    if ((rc = stage_acquire(ctx))) return rc;  // the page is free (an earlier staged copy, on whatever stream, has completed)
     hipStream_t st = static_cast<hipStream_t>(stream_);
-    BARK_HIP_CHECK(hipStreamSynchronize(st));  // the page is free (an earlier staged copy on this stream has completed)
     if ((rc = bark_forest_pack(pair26, feat_types, d, &info, ctx->stage_host))) return rc;
     BARK_HIP_CHECK(hipMemcpyAsync(ctx->stage_dev, ctx->stage_host, (size_t)info.packed_bytes, hipMemcpyHostToDevice, st));
     double *scalars_dev = reinterpret_cast<double *>(ctx->stage_dev + SCALARS_AT);
     rc = bark_tree_swap_eval_hip(ctx, K_inv, N, ctx->stage_dev, &info, X, d, info_old.max_bits, s, y, scalars_dev, workspace,
                                  workspace_bytes, stream_);
-    if (rc) return rc;
+    if (rc) {  // kernels that read the device page may be enqueued already: the next staged call waits for them
+        (void)stage_release(ctx, st);
+        return rc;
+    }
     BARK_HIP_CHECK(hipMemcpyAsync(ctx->stage_host + SCALARS_AT, scalars_dev, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     BARK_HIP_CHECK(hipStreamSynchronize(st));
     std::memcpy(scalars_host_out, ctx->stage_host + SCALARS_AT, 2 * sizeof(double));

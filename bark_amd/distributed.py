@@ -85,30 +85,65 @@ def reduce_mixture(mu_local, var_local, total: int, group=None):
 # The same two exchanges through the C ABI (include/bark_hip.h: bark_comm_* / bark_allgather_mll / bark_allreduce_f64):
 # RCCL without torch.distributed.  Opt-in (`bench.py` with BARK_BENCH_BACKEND=abi); the default stays torch.distributed.
 # ----------------------------------------------------------------------------------------------------------------------
+def _id_token() -> bytes:
+    """32 bytes every rank of ONE job derives alike and a stray local process does not know: $BARK_RCCL_ID_TOKEN (bench.py's
+    launcher draws 128 random bits per job and exports them to its workers), else the job's rendezvous identity (torchrun's
+    run id + MASTER_ADDR:MASTER_PORT — not secret, but not what an unrelated connection sends either)."""
+    import hashlib
+    import os
+
+    tok = os.environ.get("BARK_RCCL_ID_TOKEN") or "|".join(
+        os.environ.get(k, "") for k in ("TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT"))
+    return hashlib.sha256(("bark-rccl-id:" + tok).encode()).digest()
+
+
 def exchange_unique_id(rank: int, world: int, addr: str, port: int, make_id, timeout: float = 120.0) -> bytes:
     """Rank 0 makes the 128-byte RCCL unique id (`make_id()`) and hands it to the other ranks over TCP (they connect to
-    addr:port, retrying until rank 0 listens).  Plain sockets: no process group is needed to build one."""
+    addr:port, retrying until rank 0 listens).  Plain sockets: no process group is needed to build one.  A peer has to
+    present the job's token (`_id_token`) first: a connection that does not — a port scanner, another job's rank on the same
+    port — is closed without the id and does not count towards the world - 1 peers rank 0 serves."""
+    import hmac
     import socket
     import time
 
     if world == 1:
         return make_id()
+    token = _id_token()
     if rank == 0:
         uid = make_id()
+        deadline = time.monotonic() + timeout
         with socket.socket() as srv:
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             srv.bind((addr, port))
-            srv.listen(world)
-            srv.settimeout(timeout)
-            for _ in range(world - 1):
+            srv.listen(world + 8)
+            served = 0
+            while served < world - 1:
+                left = deadline - time.monotonic()
+                if left <= 0:
+                    raise TimeoutError("exchange_unique_id: %d of %d peers presented the job's token in %.0f s"
+                                       % (served, world - 1, timeout))
+                srv.settimeout(left)
                 conn, _peer = srv.accept()
                 with conn:
-                    conn.sendall(uid)
+                    conn.settimeout(5.0)
+                    try:
+                        got = b""
+                        while len(got) < len(token):
+                            part = conn.recv(len(token) - len(got))
+                            if not part:
+                                break
+                            got += part
+                        if hmac.compare_digest(got, token):
+                            conn.sendall(uid)
+                            served += 1
+                    except OSError:
+                        pass  # a stray or stalled connection: dropped, the id stays here
         return uid
     deadline = time.monotonic() + timeout
     while True:
         try:
             with socket.create_connection((addr, port), timeout=5.0) as c:
+                c.sendall(token)
                 buf = b""
                 while len(buf) < 128:
                     part = c.recv(128 - len(buf))
@@ -135,7 +170,8 @@ class RcclGroup:
         self._comm = None
         if port is None:
             # next to the launcher's rendezvous port, so that two jobs on one host do not meet on a fixed number (the id is
-            # handed to whoever connects: keep addr on the loopback / a private interface)
+            # handed only to peers that present the job's token, exchange_unique_id; still keep addr on the loopback / a
+            # private interface)
             port = int(os.environ.get("BARK_RCCL_ID_PORT", 0)) or (int(os.environ.get("MASTER_PORT", 29500)) + 33) % 65536 or 29533
         lib = _lib.lib()
 

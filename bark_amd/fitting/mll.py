@@ -301,6 +301,22 @@ def batched_mll(forest, noise, scale, X, y, feat_types, *, include_scale: bool, 
     return out if return_device else out.cpu().numpy()
 
 
+def schedule_plan(N: int, B: int, *, C: int = 0, chunk: int | None = None, m: int = 50, leaf_words: int = 5,
+                  timing: bool = False) -> dict:
+    """Which launch schedule the dense sweep takes for B forests of m trees on N points (+ C candidates), `chunk` resident at
+    a time (default: all) — `bark_mll_plan_query`, the function the entry point itself configures its sweep from (DESIGN.md
+    section 4 has the table).  Nothing on the reference's side corresponds to it (`inv` + `slogdet`,
+    examples/mcmc/mcmc_record_mll.py:63-73, have one schedule).  leaf_words: `bark_leaf_words` of the forests (5 for 50 prior
+    trees).  No GPU needed."""
+    import ctypes
+
+    plan = _lib.MllPlan()
+    _lib.check(_lib.lib().bark_mll_plan_query(N, C, m, B, chunk or B, leaf_words, int(timing), ctypes.byref(plan)))
+    d = {n: int(getattr(plan, n)) for n, _ in _lib.MllPlan._fields_}
+    d["schedule"], d["last_schedule"] = _lib.SCHEDULES[d["schedule"]], _lib.SCHEDULES[d["last_schedule"]]
+    return d
+
+
 def mll(model, data, domain):
     """examples/mcmc/mcmc_record_mll.py:57-74 — same signature; `domain` may be the feat_types array."""
     forest, noise, _scale = model

@@ -94,10 +94,11 @@ def launch(args) -> int:
     if live:  # rank 0 hands its JSON line to this process instead of printing it: see live_traffic()
         fd, line_file = tempfile.mkstemp(prefix="bark_bench_line_", suffix=".json")
         os.close(fd)
+    job_token = os.environ.get("BARK_RCCL_ID_TOKEN") or os.urandom(16).hex()  # bark_amd.distributed.exchange_unique_id
     for r in range(n):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BARK_BENCH_WORKER="1")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BARK_BENCH_WORKER="1", BARK_RCCL_ID_TOKEN=job_token)
         if line_file:
             env["BARK_BENCH_LINE_FILE"] = line_file
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this host
@@ -900,25 +901,11 @@ def sampler_step_probe(args, wl):
         if nc == 1 and args.cpu_sample > 0:  # the oracle's restated chain (quick_inverse.py:13-38) on the same proposals
             from oracle import oracle as orc
 
-            K = orc.forest_gram_matrix(cur[0], X, X, ft)
-            K[np.diag_indices(N)] += 1e-6 + 0.1
-            K_inv = np.linalg.inv(K)
-            logdet = np.linalg.slogdet(K)[1]
-            s_sqrtm = np.sqrt(1.0 / m)
-            n_cpu = 3
-            t = time.perf_counter()
-            for ti in range(n_cpu):
-                U_old = s_sqrtm * orc.get_leaf_vectors(cur[0, ti], X, ft)
-                U_new = s_sqrtm * orc.get_leaf_vectors(prop[0, ti], X, ft)
-                K1 = orc.low_rank_inv_update(K_inv, U_old, subtract=True)
-                d1 = orc.low_rank_det_update(K_inv, U_old, logdet, subtract=True)
-                K2 = orc.low_rank_inv_update(K1, U_new)
-                d2 = orc.low_rank_det_update(K1, U_new, d1)
-                orc.mll(K2, d2, y)
-            cpu = (time.perf_counter() - t) / n_cpu
-            out["cpu_oracle"] = {"ms_per_tree_proposal": 1e3 * cpu, "cores": host_cores(), "kind": "port",
-                                 "sample": "%d tree proposals of chain 0 through the oracle's subtract/add Woodbury chain "
-                                           "(numpy, N x N copies as the reference makes)" % n_cpu}
+            cpu, n_cpu, reps = oracle_chain_ms(orc, cur[0], prop[0], X, y, ft, m, n_props=3, reps=5)
+            out["cpu_oracle"] = {"ms_per_tree_proposal": cpu, "cores": host_cores(), "kind": "port",
+                                 "sample": "median of %d repetitions (after one un-timed warm-up pass) of %d tree proposals of "
+                                           "chain 0 through the oracle's subtract/add Woodbury chain (numpy, N x N copies as "
+                                           "the reference makes)" % (reps, n_cpu)}
         del cb
         torch.cuda.empty_cache()
     # the regime BARK itself samples in (tens to hundreds of points, one chain): a proposal is a chain of five small dependent
@@ -943,22 +930,43 @@ def sampler_step_probe(args, wl):
         if args.cpu_sample > 0:
             from oracle import oracle as orc
 
-            K = orc.forest_gram_matrix(cur[0], Xs, Xs, fts)
-            K[np.diag_indices(Ns)] += 1e-6 + 0.1
-            K_inv, logdet = np.linalg.inv(K), np.linalg.slogdet(K)[1]
-            t = time.perf_counter()
-            for ti in range(10):
-                U_old = np.sqrt(1.0 / m) * orc.get_leaf_vectors(cur[0, ti], Xs, fts)
-                U_new = np.sqrt(1.0 / m) * orc.get_leaf_vectors(prop[0, ti], Xs, fts)
-                K1 = orc.low_rank_inv_update(K_inv, U_old, subtract=True)
-                d1 = orc.low_rank_det_update(K_inv, U_old, logdet, subtract=True)
-                K2 = orc.low_rank_inv_update(K1, U_new)
-                orc.mll(K2, orc.low_rank_det_update(K1, U_new, d1), ys)
-            row["cpu_oracle_ms_per_tree_proposal"] = 1e3 * (time.perf_counter() - t) / 10
+            # warmed and repeated (ten un-warmed iterations right after GPU work once read 14.2 ms at
+            # N = 128 against 0.80 ms at N = 512 — the first LAPACK calls of the process, not the chain)
+            row["cpu_oracle_ms_per_tree_proposal"], n_cpu, reps = oracle_chain_ms(orc, cur[0], prop[0], Xs, ys, fts, m, n_props=10, reps=7)
+            row["cpu_oracle_sample"] = "median of %d repetitions of %d proposals, one warm-up pass" % (reps, n_cpu)
         small["N=%d" % Ns] = row
         del cb
     out["small_n_one_chain"] = small
     return out
+
+
+def oracle_chain_ms(orc, cur, prop, X, y, ft, m, n_props, reps):
+    """The oracle's restatement of one tree proposal of `_step_bark_sampler` (bark_sampler.py:233-257 with
+    quick_inverse.py:13-38: two get_leaf_vectors, subtract / add low_rank_inv_update + low_rank_det_update, mll) on the host:
+    ms per proposal = MEDIAN over `reps` timed passes of the first `n_props` trees, after one un-timed pass that pays for
+    the first LAPACK calls, thread-pool start-up and page faults of the N x N temporaries.  -> (ms, n_props, reps)"""
+    import numpy as np
+
+    N = X.shape[0]
+    K = orc.forest_gram_matrix(cur, X, X, ft)
+    K[np.diag_indices(N)] += 1e-6 + 0.1
+    K_inv, logdet = np.linalg.inv(K), np.linalg.slogdet(K)[1]
+    s_sqrtm = np.sqrt(1.0 / m)
+
+    def one_pass():
+        t = time.perf_counter()
+        for ti in range(n_props):
+            U_old = s_sqrtm * orc.get_leaf_vectors(cur[ti], X, ft)
+            U_new = s_sqrtm * orc.get_leaf_vectors(prop[ti], X, ft)
+            K1 = orc.low_rank_inv_update(K_inv, U_old, subtract=True)
+            d1 = orc.low_rank_det_update(K_inv, U_old, logdet, subtract=True)
+            K2 = orc.low_rank_inv_update(K1, U_new)
+            orc.mll(K2, orc.low_rank_det_update(K1, U_new, d1), y)
+        return (time.perf_counter() - t) / n_props
+
+    one_pass()  # warm-up, un-timed
+    times = sorted(one_pass() for _ in range(reps))
+    return 1e3 * times[len(times) // 2], n_props, reps
 
 
 def proposal_routes_probe(wl, n_props=30):

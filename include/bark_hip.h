@@ -66,10 +66,6 @@ const char *bark_last_error(void);
  * the call costs one 2 s bound, not one per block step).  Off by default when $AMD_SERIALIZE_KERNEL / $HIP_LAUNCH_BLOCKING
  * serialise dispatch.  Never used under stream capture. */
 int bark_device_wait(int on);
-/* Test hook (tests/test_gpu_context.py): the k-th launch from now on whose status the library checks reports
- * hipErrorLaunchFailure, so that the error-return paths — helper streams forked, stream capture open — can be exercised on a
- * healthy device.  k <= 0 switches it off; returns the previous countdown.  Process-wide. */
-long bark_debug_fail_launch(long k);
 /* Host-side self-check of the workgroup -> (matrix, tile) map the sweep kernels share (XCD-aware placement: speed only, but a
  * map that skipped or doubled a pair would be a wrong result): 0 when the launch grid of `ntiles` tiles x `Bc` matrices
  * reaches every pair exactly once, else the number of pairs missed or reached twice.  No GPU needed. */
@@ -104,7 +100,10 @@ int bark_ctx_status(bark_ctx *ctx, void *stream, int32_t *cat_fault_out);
 int bark_dev_alloc(bark_ctx *ctx, size_t bytes, void **ptr_out);
 int bark_dev_free(bark_ctx *ctx, void *ptr);
 /* Host -> device on `stream`; `src_host` may be reused when the call returns (blocks of up to 64 KiB are staged through the
- * context's pinned page and copied asynchronously, larger ones are copied synchronously). */
+ * context's pinned page and copied asynchronously, larger ones are copied synchronously).  The three staged entry points of a
+ * context (this one, bark_ctx_download, bark_tree_swap_eval_host_pair) share that page and may be given different streams:
+ * each waits for the event recorded behind the previous staged copy, on whatever stream it went to, before it touches the
+ * page.  One host thread per context, as everywhere. */
 int bark_ctx_upload(bark_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes, void *stream);
 /* Device -> host; synchronises `stream`. */
 int bark_ctx_download(bark_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes, void *stream);
@@ -220,6 +219,31 @@ int bark_gram_from_leaves_hip(const uint32_t *leaf1, int64_t N, const uint32_t *
  * of the call met an invalid categorical value (see bark_ctx_status).
  * ------------------------------------------------------------------------------------- */
 size_t bark_mll_workspace_bytes(int64_t N, int64_t C, int64_t m, int64_t Bc);
+
+/* Which launch schedule bark_mll_batched_hip takes for a shape — replaces nothing in the reference (its `inv` + `slogdet`,
+ * examples/mcmc/mcmc_record_mll.py:63-73, have one schedule); a debug / documentation query: the same function the entry
+ * point itself configures its sweep from, so DESIGN.md's table of schedules per BASELINE config can be asserted by a test
+ * and a tuning constant cannot silently move a shape onto another schedule.  No GPU needed.
+ *   leaf_words: bark_leaf_words(info) of the forests (decides whether the Gram is fused into the row kernels);
+ *   timing != 0: as a call with a bark_mll_timing (the one-launch evaluation of N <= 128 is not taken then).
+ * dev_wait / dev_gate are reported as the process-wide switch stands (bark_device_wait), outside stream capture. */
+enum {
+    BARK_SCHED_ONE_BLOCK = 0,        /* N <= 128, MLL only: leaf walk + one launch per chunk */
+    BARK_SCHED_PLAIN = 1,            /* diag(j) || rows(j), then solve(j) */
+    BARK_SCHED_PAIRED = 2,           /* plain with two block rows per row launch (chunks of a multiple of 256 matrices) */
+    BARK_SCHED_PIPELINED = 3,        /* rows(j) over k < j-1 two steps ahead; consumers apply the last block row */
+    BARK_SCHED_SPLITK = 4,           /* split-K layout (A materialised, slab scratch), no look-ahead step */
+    BARK_SCHED_SPLITK_LOOKAHEAD = 5  /* split-K layout with look-ahead bulk launches */
+};
+typedef struct {
+    int32_t n_chunks, chunk, last_chunk;  /* chunks of `chunk` matrices, the last one of `last_chunk` */
+    int32_t schedule, last_schedule;      /* BARK_SCHED_* of the full chunks / of the last chunk */
+    int32_t splitk_layout, fused_gram;    /* slab scratch + materialised A; A generated inside the row kernels */
+    int32_t dev_wait, dev_gate, pre_update; /* device-side hand-over, gate kernels, diag_pre_kernel (full chunks) */
+    int32_t lookahead_steps, splitk_steps;  /* block steps with a look-ahead bulk / with any split-K launch (full chunks) */
+    int32_t nrb, ncb;                     /* block rows, block columns incl. candidate blocks */
+} bark_mll_plan;
+int bark_mll_plan_query(int64_t N, int64_t C, int64_t m, int64_t B, int64_t Bc, int leaf_words, int timing, bark_mll_plan *out);
 
 typedef struct {
     float total_ms;     /* the whole call on the caller's stream */

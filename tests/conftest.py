@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# include/bark_hip_testing.h: the launch-failure hook exists only in processes started with this variable (read when the
+# library is loaded, which no test module has done yet; child processes of the tests inherit it)
+os.environ.setdefault("BARK_TEST_HOOKS", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

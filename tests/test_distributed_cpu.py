@@ -186,3 +186,46 @@ def test_unique_id_exchange_over_tcp():
     for t in ts:
         t.join(timeout=60)
     assert got == {0: want, 1: want, 2: want}
+
+
+def test_unique_id_is_not_handed_to_a_peer_without_the_job_token():
+    """rank 0 used to send the id to whoever connected first.  A connection that does not present the job's
+    token (a stray local client — here one that sends nothing and one that sends 32 wrong bytes) gets no byte of the id and
+    does not use up a peer slot: the real rank 1, arriving later, is still served."""
+    import socket
+    import threading
+    import time
+
+    from bark_amd.distributed import exchange_unique_id
+
+    port, world = _free_port(), 2
+    want = bytes(range(128, 256))
+    got, stray = {}, []
+
+    def rank_fn(r):
+        if r == 1:
+            time.sleep(1.0)  # the strays come first
+        got[r] = exchange_unique_id(r, world, "127.0.0.1", port, lambda: want, timeout=30.0)
+
+    def stray_fn(payload):
+        deadline = time.monotonic() + 10.0
+        while time.monotonic() < deadline:
+            try:
+                with socket.create_connection(("127.0.0.1", port), timeout=2.0) as c:
+                    if payload:
+                        c.sendall(payload)
+                    c.shutdown(socket.SHUT_WR)
+                    c.settimeout(8.0)
+                    stray.append(c.recv(128))
+                    return
+            except (ConnectionRefusedError, OSError):
+                time.sleep(0.05)
+
+    ts = [threading.Thread(target=rank_fn, args=(0,)), threading.Thread(target=stray_fn, args=(b"",)),
+          threading.Thread(target=stray_fn, args=(b"x" * 32,)), threading.Thread(target=rank_fn, args=(1,))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=60)
+    assert got == {0: want, 1: want}
+    assert stray == [b"", b""], stray

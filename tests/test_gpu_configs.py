@@ -50,9 +50,10 @@ def test_c3_b256_plain_schedule():
     """configs[2], the headline shape exactly: N = 4096, d = 8, m = 50, B = 256 forests seeded 4096 + b, noise
     U[0.05, 0.15) (examples/mcmc/mcmc_record_mll.py:57-74 convention).  256 resident matrices of 32 block
     rows is the one shape class that takes Sweep's PLAIN schedule with ragged-round splitting off (bc % 256 == 0 and
-    nrb >= 16; since round 4 its row launches end with one SYRK workgroup per matrix for the diagonal tile).  First / middle
-    / last sample against the oracle's LU route, bit-reproducibility of the call, and agreement with the pipelined schedule
-    (chunk = 64)."""
+    nrb >= 16; since round 4 its row launches end with one SYRK workgroup per matrix for the diagonal tile, and two block rows
+    share a launch: `paired`).  Sixteen samples spread over the batch against the oracle's LU route (the reference's arithmetic;
+    the remaining 240 are vendor-checked in test_c3_b256_all_samples_against_vendor_cholesky), bit-reproducibility of the call,
+    and agreement with the pipelined schedule (chunk = 64)."""
     import torch
 
     import bark_amd.fitting as fit
@@ -70,15 +71,19 @@ def test_c3_b256_plain_schedule():
     assert np.array_equal(got, again)
     piped = fit.batched_mll(F, noise, None, Xd, y, ft, chunk=64, **kw)
     assert np.allclose(got, piped, rtol=1e-12, atol=0.0)
-    pick = [0, B // 2, B - 1]
+    # 16 of the 256 samples against the reference's own arithmetic (LU inv + slogdet, ~3 s of host time each): the first sample
+    # of every even group of 16 and the last of every odd one — both ends of the batch, every XCD residue (b % 8 in {0, 7}).
+    # The other 240 are checked against the vendor's Cholesky in the next test, not against the oracle.
+    pick = [16 * c + (0 if c % 2 == 0 else 15) for c in range(B // 16)]
+    assert pick[0] == 0 and pick[-1] == B - 1 and len(pick) == 16
     want = orc.batched_mll(F[pick], noise[pick], None, X, y, ft, **kw)
     assert np.allclose(got[pick], want, rtol=MLL_RTOL, atol=MLL_ATOL), (got[pick], want)
     assert np.isfinite(got).all()
 
 
 def test_c3_b256_all_samples_against_vendor_cholesky():
-    """The headline shape again, ALL 256 samples against a solver that shares nothing with the sweep (the oracle takes ~5 s per
-    sample, hence three of them in the test above): the device Gram matrices (bit-exact against the oracle in
+    """The headline shape again, ALL 256 samples against a solver that shares nothing with the sweep (the oracle takes ~3 s per
+    sample, hence sixteen of them in the test above; the other 240 have this check only): the device Gram matrices (bit-exact against the oracle in
     test_gpu_parity.py) through torch.linalg.cholesky, the vendor's batched fp64 factorisation.  A checker, like the oracle:
     nothing in the product calls it."""
     import torch
@@ -129,6 +134,32 @@ def test_n2200_b256_one_chunk_of_256():
     pick = [0, 1, 127, 128, 255]
     want = orc.batched_mll(F[pick], noise[pick], scale[pick], X, y, ft, **kw)
     assert np.allclose(got[pick], want, rtol=MLL_RTOL, atol=MLL_ATOL), (got[pick], want)
+
+
+def test_sixteen_block_rows_b256_is_the_boundary_of_the_paired_schedule():
+    """chunks of exactly 16 block rows (N = 1921..2048) x a multiple of 256 matrices sit ON the boundary of the schedule
+    rule (plan_chunk: paired from PLAIN_MIN_NRB = 16 block rows on, pipelined below) and no test covered them.  N = 2048 and
+    the ragged N = 1930 (16 block rows, the last one of 10 points) at B = 256: bit-reproducible, equal to the pipelined schedule
+    (chunk = 64) to 1e-12, five samples against the oracle's LU route; N = 1920 x 256 (15 block rows) stays pipelined."""
+    import bark_amd.fitting as fit
+    from bark_amd import synthetic as syn
+    from bark_amd.fitting import schedule_plan
+    from oracle import oracle as orc
+
+    assert schedule_plan(2048, 256)["schedule"] == "paired" and schedule_plan(1930, 256)["schedule"] == "paired"
+    assert schedule_plan(1920, 256)["schedule"] == "pipelined"
+    B, m = 256, 50
+    for N in (2048, 1930):
+        X, y, bounds, ft = syn.unit_cube_problem(N, 8, seed=N)
+        F = syn.sample_prior_forests(B, m, bounds, ft, seed=N + 1)
+        noise = np.random.default_rng(N + 2).uniform(0.05, 0.15, B)
+        kw = dict(include_scale=False, include_2pi=True)
+        got = fit.batched_mll(F, noise, None, X, y, ft, chunk=256, **kw)
+        assert np.array_equal(got, fit.batched_mll(F, noise, None, X, y, ft, chunk=256, **kw))
+        assert np.allclose(got, fit.batched_mll(F, noise, None, X, y, ft, chunk=64, **kw), rtol=1e-12, atol=0.0)
+        pick = [0, 7, 128, 200, 255]
+        want = orc.batched_mll(F[pick], noise[pick], None, X, y, ft, **kw)
+        assert np.allclose(got[pick], want, rtol=MLL_RTOL, atol=MLL_ATOL), (N, got[pick], want)
 
 
 @pytest.mark.parametrize("noise", [1e-1, 1e-4, 1e-6])
@@ -326,3 +357,34 @@ def test_c4_512_samples_sharded():
     want = orc.batched_mll(F[:1], noise[pick][:1], None, X, y, ft, include_scale=False, include_2pi=True)
     assert np.allclose(one[:1], want, rtol=MLL_RTOL, atol=MLL_ATOL)
     assert np.isfinite(results[0]).all()
+
+
+def test_schedule_plan_is_what_the_sweep_runs():
+    """the schedule table of DESIGN.md section 4 (asserted without a GPU in
+    tests/test_host_cpu.py::test_schedule_table_of_the_baseline_configs) describes what is launched: the instrumented call's
+    launch counts (bark_mll_timing) are those of the schedule bark_mll_plan_query names — the headline shape c3 runs `paired`
+    (16 row launches for 32 block rows), c4's per-GPU share `pipelined` (a row launch per block row with tiles), c2 the split-K
+    layout — and the instrumented call agrees with the production call's MLL."""
+    import torch
+
+    import bench
+    from bark_amd import _lib
+    from bark_amd.fitting import schedule_plan
+
+    #                N     B   schedule     diag panel solve launches
+    cases = ((4096, 256, "paired", 32, 16, 31), (4096, 64, "pipelined", 32, 31, 31), (1024, 1, "splitk", 8, 6, 7),
+             (512, 256, "plain", 4, 3, 3))
+    for N, B, sched, nd, npan, nsol in cases:
+        assert schedule_plan(N, B, timing=True)["schedule"] == sched, (N, B)
+        wl = bench.Workload(N, 8, 50, B, seed_base=N, rank_offset=0)
+        wl.settle_device_wait()
+        wl.run()
+        torch.cuda.synchronize()
+        want = wl.mll_d.clone()
+        t = _lib.MllTiming()
+        wl.run(timing=t)
+        torch.cuda.synchronize()
+        assert (t.n_diag_launches, t.n_panel_launches, t.n_solve_launches) == (nd, npan, nsol), (N, B, sched)
+        assert torch.allclose(wl.mll_d, want, rtol=1e-12, atol=0.0) and int(wl.info_d.abs().max().item()) == 0
+        del wl
+        torch.cuda.empty_cache()

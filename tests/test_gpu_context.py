@@ -616,11 +616,18 @@ import os, sys, time
 sys.path.insert(0, {root!r})
 import torch, bench
 from bark_amd import _lib
+lib = _lib.lib()
 wl = bench.Workload(1100, 8, 50, 8, seed_base=1100, rank_offset=0)
+fallbacks = 0
 for _ in range(40):
     wl.run()
-torch.cuda.synchronize()
-print("STATE", bench.device_wait_state(_lib.lib()), "INFO", int(wl.info_d.abs().max().item()))
+    torch.cuda.synchronize()
+    if bool((wl.info_d == -3).any().item()):  # a bounded wait ran out: the documented fallback (include/bark_hip.h, bark_device_wait)
+        fallbacks += 1
+        lib.bark_device_wait(0)
+        wl.run()
+        torch.cuda.synchronize()
+print("STATE", bench.device_wait_state(lib), "INFO", int(wl.info_d.abs().max().item()), "FALLBACKS", fallbacks)
 print("MLL", wl.mll_d.cpu().numpy().tobytes().hex())
 """
 
@@ -628,11 +635,14 @@ print("MLL", wl.mll_d.cpu().numpy().tobytes().hex())
 def test_device_wait_with_four_processes_on_one_gpu(env):
     """VERDICT r3 "what's weak" 8: the device-side hand-over had never run with several PROCESSES on a card (eight ranks on a node
     is where helper-stream concurrency may differ).  Four processes at once on this GPU, each 40 sweeps of a chunk of 8 matrices
-    (device-side waits in every block step) while this process keeps a fifth stream of the same work going: every process reports
-    the mechanism still on (a time-out would have switched it off), info == 0, and the bits of an undisturbed run."""
+    (device-side waits in every block step) while this process keeps a fifth stream of the same work going: every process ends
+    with info == 0 and the bits of an undisturbed run, and says whether a wait ever ran into its bound (then it took the
+    documented fallback; on the boxes so far none did).  The loop has a wall-clock deadline and the children are reaped on
+    every exit."""
     import os
     import subprocess
     import sys
+    import time
 
     import bench
 
@@ -644,17 +654,42 @@ def test_device_wait_with_four_processes_on_one_gpu(env):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     procs = [subprocess.Popen([sys.executable, "-c", _CONTENDED_SCRIPT.format(root=root)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                               text=True) for _ in range(4)]
-    while any(p.poll() is None for p in procs):  # the parent competes for the card as well
-        wl.run()
-        torch.cuda.synchronize()
-    assert int(wl.info_d.abs().max().item()) == 0 and wl.mll_d.cpu().numpy().tobytes().hex() == want
-    for p in procs:
-        out, err = p.communicate(timeout=60)
-        assert p.returncode == 0, err[-2000:]
-        state = [ln for ln in out.splitlines() if ln.startswith("STATE")][0].split()
-        assert state[1] == "on" and int(state[3]) == 0, state
-        assert [ln for ln in out.splitlines() if ln.startswith("MLL")][0].split()[1] == want
-    assert bench.device_wait_state(env.lib.lib()) == "on"
+    deadline = time.monotonic() + 300.0  # four children x 40 sweeps of ~1 ms + start-up: minutes would mean a hang
+    lib, parent_fallbacks = env.lib.lib(), 0
+    try:
+        while any(p.poll() is None for p in procs):  # the parent competes for the card as well
+            assert time.monotonic() < deadline, "a child process is still running after 300 s"
+            wl.run()
+            torch.cuda.synchronize()
+            if bool((wl.info_d == -3).any().item()):  # the parent takes the documented fallback like its children
+                parent_fallbacks += 1
+                lib.bark_device_wait(0)
+                wl.run()
+                torch.cuda.synchronize()
+        assert int(wl.info_d.abs().max().item()) == 0 and wl.mll_d.cpu().numpy().tobytes().hex() == want
+        outcomes = [("parent", parent_fallbacks)]
+        for p in procs:
+            out, err = p.communicate(timeout=60)
+            assert p.returncode == 0, err[-2000:]
+            state = [ln for ln in out.splitlines() if ln.startswith("STATE")][0].split()
+            # bits: always those of an undisturbed run.  Whether a 2 s wait ever ran out with five processes on the card's
+            # queues is a property of the box's scheduling, not of the code: a child that took the documented fallback
+            # (info == -3, mechanism off, same call again) reports it, and must then have ended with the mechanism off
+            assert int(state[3]) == 0, state
+            assert (state[1] == "on") == (int(state[5]) == 0), state
+            assert [ln for ln in out.splitlines() if ln.startswith("MLL")][0].split()[1] == want
+            outcomes.append((state[1], int(state[5])))
+        print("device-side wait under five processes: (state, fallbacks) per child =", outcomes)
+    finally:
+        lib.bark_device_wait(1)  # process-wide switch: later tests expect the default
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except Exception:  # noqa: BLE001
+                pass
 
 
 def test_device_wait_from_a_side_stream_and_from_two_threads(env):

@@ -17,7 +17,9 @@ LEAF, CAT, FEAT = 0x80000000, 0x40000000, 0x3FFFFFFF
 
 
 def test_library_exports_every_declared_symbol():
-    header = open(os.path.join(ROOT, "include", "bark_hip.h")).read()
+    # every header under include/: the drop-in boundary (bark_hip.h) and the test-suite's own hooks (bark_hip_testing.h)
+    inc = os.path.join(ROOT, "include")
+    header = "".join(open(os.path.join(inc, f)).read() for f in sorted(os.listdir(inc)) if f.endswith(".h"))
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     declared = set(re.findall(r"\b(bark_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
@@ -328,3 +330,47 @@ def test_workgroup_to_tile_map_reaches_every_pair_once():
         for ntiles in (1, 2, 3, 7, 8, 15, 31, 32, 100, 248):
             assert lib.bark_xcd_map_selftest(ntiles, Bc) == 0, (ntiles, Bc)
     assert lib.bark_xcd_map_selftest(0, 4) == -1
+
+
+# DESIGN.md section 4 "Which schedule runs": (N, B, C, chunk) -> (schedule, fused Gram, device-side wait, gates, diag_pre_kernel)
+SCHEDULE_TABLE = {
+    "c1 N=64 x 1": ((64, 1, 0, None), ("one_block", 1, 0, 0, 0)),
+    "c2 N=1024 x 1": ((1024, 1, 0, None), ("splitk", 0, 1, 0, 1)),
+    "c3 N=4096 x 256": ((4096, 256, 0, None), ("paired", 1, 0, 0, 0)),
+    "c4 share N=4096 x 64": ((4096, 64, 0, None), ("pipelined", 1, 0, 0, 0)),
+    "c4 on one GPU, N=4096 x 512 in chunks of 256": ((4096, 512, 0, 256), ("paired", 1, 0, 0, 0)),
+    "c5 N=16384 x 1": ((16384, 1, 0, None), ("pipelined", 1, 1, 1, 0)),
+    "c5 posterior, 10^4 candidates": ((16384, 1, 10000, None), ("pipelined", 0, 1, 1, 0)),
+    "c5 B=4 variant": ((16384, 4, 0, None), ("pipelined", 1, 1, 1, 0)),
+    "lone N=4096": ((4096, 1, 0, None), ("splitk", 0, 1, 0, 1)),
+    "N=4096 x 8": ((4096, 8, 0, None), ("pipelined", 1, 1, 1, 0)),
+    "N=4096 x 16": ((4096, 16, 0, None), ("pipelined", 1, 1, 1, 0)),
+    "N=2048 x 256 (16 block rows)": ((2048, 256, 0, None), ("paired", 1, 0, 0, 0)),
+    "N=1920 x 256 (15 block rows)": ((1920, 256, 0, None), ("pipelined", 1, 0, 0, 0)),
+    "N=512 x 256": ((512, 256, 0, None), ("plain", 1, 0, 0, 0)),
+    "N=256 x 256": ((256, 256, 0, None), ("plain", 1, 0, 0, 0)),
+    "N=64 x 256": ((64, 256, 0, None), ("one_block", 1, 0, 0, 0)),
+    "lone N=6900 (look-ahead)": ((6900, 1, 0, None), ("splitk_lookahead", 0, 1, 1, 1)),
+}
+
+
+def test_schedule_table_of_the_baseline_configs():
+    """which of Sweep's schedules each BASELINE config (and each `configs` row of the bench line) takes, asked
+    through the ABI (bark_mll_plan_query = the function bark_mll_batched_hip configures its sweep from) — a changed tuning
+    constant that moves a shape, above all the headline c3 off the paired schedule, fails here.  No GPU needed."""
+    from bark_amd.fitting import schedule_plan
+
+    prev = _lib.lib().bark_device_wait(1)  # the table is for the default (mechanism on)
+    try:
+        for name, ((N, B, C, chunk), want) in SCHEDULE_TABLE.items():
+            d = schedule_plan(N, B, C=C, chunk=chunk)
+            got = (d["schedule"], d["fused_gram"], d["dev_wait"], d["dev_gate"], d["pre_update"])
+            assert got == want, (name, got, want)
+            assert d["last_schedule"] == d["schedule"], name
+        d = schedule_plan(4096, 300, chunk=256)  # a ragged last chunk takes its own schedule
+        assert (d["n_chunks"], d["last_chunk"], d["schedule"], d["last_schedule"]) == (2, 44, "paired", "pipelined")
+        assert schedule_plan(64, 1, timing=True)["schedule"] == "plain"  # the instrumented call has no one-launch form
+        _lib.lib().bark_device_wait(0)
+        assert schedule_plan(1024, 1)["dev_wait"] == 0 and schedule_plan(4096, 8)["dev_gate"] == 0
+    finally:
+        _lib.lib().bark_device_wait(prev)
