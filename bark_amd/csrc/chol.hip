@@ -1891,10 +1891,6 @@ constexpr int SPLITK_LAYOUT_MAX_TILES = BARK_SPLITK_LAYOUT_MAX_TILES;
 constexpr int64_t SPLITK_LAYOUT_MAX_WORK = BARK_SPLITK_LAYOUT_MAX_WORK;
 // Build-time tuning constants of the pipelined schedule (numbers only: every on/off alternative that was measured and
 // lost is gone from the sources, with its figures left in the comment next to the code that won).
-#ifndef BARK_PIPE_PLAIN_WORK
-#define BARK_PIPE_PLAIN_WORK 0
-#endif
-constexpr long PIPE_PLAIN_WORK = BARK_PIPE_PLAIN_WORK;  // see plan_chunk / Sweep::plain_until (0: pipelined from block row 0)
 #ifndef BARK_PIPE_MIN_NRB
 #define BARK_PIPE_MIN_NRB 8
 #endif
@@ -2496,15 +2492,7 @@ struct Sweep {
     //   caller's stream  diag(j) -> [wait bulk(j)] solve(j) -> diag(j+1) -> ...
     //   helper streams   bulk(j+2) after solve(j)
     // Every bulk launch is awaited on the caller's stream at its own step, so the pattern stays fork/join (capturable).
-    // plain_until (round 5): the first block steps of a pipelined chunk keep the WHOLE K range in their row launch
-    // (kdone(j) = j for j < plain_until: launched after solve(j-1), beside diag(j), plain solve) — while the row work of a step
-    // is short, the step is bound by the chain diag -> solve -> diag, and deferring the last block row makes exactly that chain
-    // longer (diag_kernel with two block rows and the G block, a K = 256 solve: 2.8 x the plain solve's flops) for an overlap
-    // nothing needs yet.  From plain_until on the launches go out two steps ahead as described above; the consumers read how
-    // many block rows a stored tile lacks from kdone(), so the two forms mix freely.  See plan_chunk for the rule.
-    int plain_until = 0;
-    int next_bulk = 0;  // first block row whose row launch has not been enqueued yet
-    int kdone(int j) const { return j < plain_until ? j : (j > 0 ? j - 1 : 0); }
+    int kdone(int j) const { return j > 0 ? j - 1 : 0; }
     int tiles_of(int j) const { return (ncb - j - 1) + ((j + 1 < nrb) ? 1 : 0); }
     // a K = 0 launch only generates A (fused sweeps); with a materialised A there is nothing to do
     bool has_bulk(int j) const { return j < nrb_steps && tiles_of(j) > 0 && (kdone(j) > 0 || fused); }
@@ -2512,9 +2500,8 @@ struct Sweep {
         if (!has_bulk(j)) return BARK_OK;
         hipStream_t st = (j & 1) ? la_stream : panel;  // one bulk stream only: B = 256 at N = 4096 94 -> 100 ms
         int r;
-        // called right after solve(done), done = kdone(j) - 1: diag_kernel(done + 1), next on `main`, publishes done + 2 when it starts
-        if (dev_gate && kdone(j) >= 1) {
-            if ((r = gate(st, kdone(j) + 1))) return r;
+        if (dev_gate && j >= 2) {  // called right after solve(j-2): diag_kernel(j-1), next on `main`, publishes j when it starts
+            if ((r = gate(st, j))) return r;
         } else {
             BARK_HIP_CHECK(hipEventRecord(res->events[6 * j + 3], main));
             if ((r = after(st, res->events[6 * j + 3]))) return r;
@@ -2555,9 +2542,8 @@ struct Sweep {
                 BARK_HIP_CHECK(hipEventRecord(res->events[5], main));
                 if ((r = after(panel, res->events[5])) || (r = after(la_stream, res->events[5]))) return r;
             }
-            next_bulk = 0;
-            for (; next_bulk < nrb_steps && kdone(next_bulk) == 0; ++next_bulk)  // block row 0, and 1 unless it is a plain step
-                if ((r = launch_bulk(next_bulk))) return r;
+            if ((r = launch_bulk(0))) return r;
+            if ((r = launch_bulk(1))) return r;
         }
         // the stored P_jj comes from the row launch of block row j-1: block rows kdone(j-1) .. j-1 are still to apply
         const bool deferred = j > kdone(j);
@@ -2592,10 +2578,7 @@ struct Sweep {
             if ((r = mark_on(main))) return r;
             solve_flops += ((deferred ? 32.0 : 0.0) + 18.0) / 32.0 * 2.0 * NB * NB * (double)NB * (double)n_right * (double)bc;
         }
-        // the row launches that only waited for solve(j): block row j+1 if it is a plain step, j+2 (or j+1, j+2 at the change-over)
-        for (; next_bulk < nrb_steps && kdone(next_bulk) <= j + 1; ++next_bulk)
-            if ((r = launch_bulk(next_bulk))) return r;
-        return BARK_OK;
+        return launch_bulk(j + 2);
     }
 
     // fill *t from the recorded events (synchronises); [t_begin, t_end] bracket the whole call on `caller`
@@ -2640,13 +2623,11 @@ struct Sweep {
 struct ChunkPlan {
     bool one_block, pipelined, paired, dev_wait, dev_gate, pre_update;
     int lookahead_steps, splitk_steps;
-    int plain_until;  // pipelined schedule: block steps [0, plain_until) keep their whole K range in the row launch (Sweep::kdone)
 };
 ChunkPlan plan_chunk(Sweep &sw, int64_t bc, int64_t C, bool timing, bool dev_wait_ok, bool two_streams) {
     ChunkPlan c{};
     const int nrb = sw.nrb;
     const bool splitk = sw.splitk;
-    sw.plain_until = 0;
     // Pipelined schedule: pays whenever the plain schedule leaves ragged rounds of workgroups (measured at N = 4096:
     // B = 40 +15 %, 64 +7 %, 96 +9 %, 160 +5 %, 192 +4 %; N = 8192, B = 32 +7 %; N = 2048, B = 128..192 +5 %).  When Bc
     // is a multiple of the 256 CUs every round of the plain schedule is full or exactly half full; the two then tie at
@@ -2677,17 +2658,6 @@ ChunkPlan plan_chunk(Sweep &sw, int64_t bc, int64_t C, bool timing, bool dev_wai
         }
         if (c.dev_wait && c.lookahead_steps > 0) c.dev_gate = true;
     } else if (c.pipelined) {
-        // Sweep::plain_until: the pipelined form from the first block step on whose row launch holds PIPE_PLAIN_WORK
-        // tile x block-row products (4.2 MFLOP each: 2400 of them are ~150 us of the whole chip at the row kernel's rate, about
-        // what the deferred chain diag(two block rows + G) -> K = 256 solve costs beside resident row workgroups)
-        sw.plain_until = 0;
-        if (PIPE_PLAIN_WORK > 0) {
-            int jj = 1;
-            for (; jj < nrb; ++jj)
-                if ((long)sw.tiles_of(jj) * bc * (jj - 1) >= PIPE_PLAIN_WORK) break;
-            sw.plain_until = jj;
-        }
-        c.plain_until = sw.plain_until;
         for (int jj = 0; jj < nrb; ++jj) {
             const int k = sw.kdone(jj), nt = sw.tiles_of(jj);
             if (sw.has_bulk(jj) && k >= 2 && nt * (int)bc < SPLITK_SLOTS / 2 && (2 * PIPE_BULK_SLOTS + nt * (int)bc) / (2 * nt * (int)bc) >= 2)

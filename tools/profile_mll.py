@@ -15,6 +15,9 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 C = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 wl = bench.Workload(N, 8, 50, B, seed_base=N, rank_offset=0, C=C, problem="mixed" if C else "unit")
 avg, med = wl.device_ms(steps, warm=1)
+digest = ""
 if not os.environ.get("BARK_PROFILE_NOCHECK"):  # timing-only ablation builds produce finite garbage
-    wl.check()
-print(f"N={N} B={B} C={C}: {med:.3f} ms per call (median of {steps}), lib={os.environ.get('BARK_LIB_PATH', 'product')}")
+    import hashlib
+
+    digest = " mll=" + hashlib.sha256(wl.check().tobytes()).hexdigest()[:10]  # bit-identity of variants across processes
+print(f"N={N} B={B} C={C}: {med:.3f} ms per call (median of {steps}), lib={os.environ.get('BARK_LIB_PATH', 'product')}{digest}")
