@@ -140,12 +140,24 @@ __global__ __launch_bounds__(WALK_THREADS) void leaf_walk_kernel(const uint4 *__
     }
 }
 
-// Small grids (a lone matrix, c2: fewer workgroups than CUs): the walk is a chain of m dependent tree walks per thread
-// and nothing else runs beside it, so the trees of a point are shared out over WALK_GROUPS threads — 32 points per
-// workgroup, 8 x the workgroups, an eighth of the chain each (N = 1024, one forest: 29 -> 8 us).  Same walks, same
+// Small grids (a lone matrix, c2, a few hundred small matrices: fewer than 8 workgroups per CU): the walk is a chain of m
+// dependent tree walks per thread and too little runs beside it, so the trees of a point are shared out over WALK_GROUPS threads
+// — 32 points per workgroup, 8 x the workgroups, an eighth of the chain each (N = 1024, one forest: 29 -> 8 us).  Same walks, same
 // integer results.  MODE 2: the groups OR their bits into the point's words in LDS; MODE 1: a word (4 trees) belongs to
 // one group.
 constexpr int WALK_GROUPS = 8, WALK_POINTS = WALK_THREADS / WALK_GROUPS;
+// Which grids: every one that would leave the one-thread-per-point kernel fewer than 8 workgroups per CU.  That kernel is a
+// chain of m dependent walks (each two or three dependent 16-byte loads) per thread, and with one wave per SIMD nothing hides
+// them: 256 forests x 256 points — exactly one workgroup per CU, so the old rule (fewer workgroups than CUs) passed it by —
+// took 47 us of a 187 us evaluation (profiles/r05/small_n.txt).  Round 5, same box, one process per variant, device ms of the
+// whole MLL call, threshold 256 | 1024 | 4096 | none: N = 64 x 256 forests 0.053 | 0.036 | 0.035 | 0.036, N = 128 x 256 0.077 | 0.059 |
+// 0.059 | 0.059, N = 256 x 256 0.187 | 0.157 | 0.158 | 0.156, N = 512 x 256 0.554 | 0.522 | 0.515 | 0.530, N = 1024 x 64 1.050 | 1.003 |
+// 1.014 | 1.005, N = 4096 x 16 7.006 | 6.938 | 6.933 | 6.966; N = 64 x 2048 (a grid of 2048) 0.155 | 0.155 | 0.165 | 0.166 — with 8 workgroups
+// per CU the plain kernel hides its chains itself.  Identical integer results (the MLL digests of the A/B agree).
+#ifndef BARK_WALK_GROUPED_MAX_WGS
+#define BARK_WALK_GROUPED_MAX_WGS 2048
+#endif
+constexpr int64_t WALK_GROUPED_MAX_WGS = BARK_WALK_GROUPED_MAX_WGS;  // grids of the one-thread-per-point kernel below this take the grouped one
 template <int MODE>
 __global__ __launch_bounds__(WALK_THREADS) void leaf_walk_grouped_kernel(const uint4 *__restrict__ nodes, int stride, int m,
                                                                          int max_depth, const double *__restrict__ X, int N,
@@ -224,7 +236,7 @@ int launch_walk(const void *packed, const bark_pack_info *info, const double *X,
     const uint4 *nodes = static_cast<const uint4 *>(packed);
     if constexpr (MODE != 0) {
         const size_t glds = (size_t)WALK_POINTS * (d | 1) * sizeof(double) + (MODE == 2 ? (size_t)WALK_POINTS * words * sizeof(uint32_t) : 0);
-        if ((int64_t)grid.x * grid.y < 256 && glds <= 64 * 1024) {  // fewer workgroups than CUs: share a point's trees out
+        if ((int64_t)grid.x * grid.y < WALK_GROUPED_MAX_WGS && glds <= 64 * 1024) {  // too few workgroups to hide the chains: share a point's trees out
             const dim3 gg((unsigned)((npad + WALK_POINTS - 1) / WALK_POINTS), (unsigned)info->B);
             hipLaunchKernelGGL((leaf_walk_grouped_kernel<MODE>), gg, dim3(WALK_THREADS), glds, s, nodes, (int)info->stride,
                                (int)info->m, (int)info->max_depth, X, (int)N, (int)d, (int)npad, words, out, fault);
