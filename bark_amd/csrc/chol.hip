@@ -49,6 +49,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -76,6 +77,15 @@ int launch_gram(const uint32_t *leaf1, int npad1, const uint32_t *leaf2, int npa
                 int64_t batch_stride, bool pad_identity, bool upper_only, int rep, int words, hipStream_t stream);
 
 namespace {
+
+// Tuning builds only (-DBARK_DIAG_STAMPS; tools/ab/diag_stamps.py): cycle stamps of thread 0 of workgroup 0 of the diagonal-block
+// kernels.  Without the flag the macro is empty.
+#ifdef BARK_DIAG_STAMPS
+__device__ unsigned long long g_diag_stamps[64];
+#define DIAG_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_diag_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DIAG_STAMP(i) do {} while (0)
+#endif
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -536,36 +546,86 @@ struct OneBlock {
     int include_2pi, rep;  // MLL convention; leaf-code encoding (LeafRep)
 };
 
-__device__ __forceinline__ uint32_t code_count_rt(int rep, uint32_t a, uint32_t b) {
-    return rep == REP_BITS ? code_count<REP_BITS>(a, b) : rep == REP_BYTES7 ? code_count<REP_BYTES7>(a, b) : code_count<REP_BYTES8>(a, b);
+// What every generated entry of matrix b needs besides the two points' codes — read ONCE per kernel phase (gen_ctx): as a
+// per-entry read of p.scale[b] / p.shift[b] / p.noise[b] and a per-entry 1.0 / m the generation of a 128 x 128 tile's upper
+// block triangle took 57 K cycles (24 us) of the one-launch kernels, most of it global-load latency (round 5,
+// profiles/r05/small_n.txt).
+struct GenCtx {
+    double inv_m, sc, sh, jitter;
+    int has_scale, has_shift, rep, nW, N, m;
+};
+__device__ __forceinline__ GenCtx gen_ctx(const Mats &p, int b, int rep) {
+    GenCtx g;
+    g.inv_m = 1.0 / (double)p.m;
+    g.has_scale = p.scale != nullptr;
+    g.has_shift = p.shift != nullptr;
+    g.sc = g.has_scale ? p.scale[b] : 1.0;
+    g.sh = g.has_shift ? p.shift[b] : 0.0;
+    g.jitter = 1e-6 + p.noise[b];
+    g.rep = rep;
+    g.nW = p.nW;
+    g.N = p.N;
+    g.m = p.m;
+    return g;
 }
-// A[gi][gj] of matrix b from the leaf codes staged in LDS (codes[w][128]): form_tile's arithmetic, operation for operation
-__device__ __forceinline__ double gen_entry(const Mats &p, int b, int rep, const uint32_t *codes, int gi, int gj) {
-    if (gi >= p.N || gj >= p.N) return gi == gj ? 1.0 : 0.0;  // identity padding
-    uint32_t cnt = 0;
-    for (int w = 0; w < p.nW; ++w) cnt += code_count_rt(rep, codes[w * NB + gi], codes[w * NB + gj]);
-    const int agree = rep == REP_BITS ? (int)cnt : p.m - (int)cnt;
-    double val = (1.0 / (double)p.m) * (double)agree;
-    if (p.shift) val = val - p.shift[b];
-    if (p.scale) val = p.scale[b] * val;
-    if (gi == gj) val = val + (1e-6 + p.noise[b]);
-    return val;
+// A[gi[v]][gj], v = 0..3, of the matrix from the leaf codes staged in LDS (codes[w][cs]: cs points per code plane — 128 for one
+// block row, 256 for two; planes are zero beyond the last point): form_tile's arithmetic, operation for operation.  The code
+// words go round the OUTSIDE — one pass over the planes serves the four rows, five LDS reads per word with four independent
+// counts — where an entry at a time was a chain of dependent LDS round trips per entry (36 of them per lane and tile).
+template <int REP>
+__device__ __forceinline__ void gen_counts4(const uint32_t *codes, int cs, int nW, const int (&gi)[4], int gj, uint32_t (&cnt)[4]) {
+    for (int w = 0; w < nW; ++w) {
+        const uint32_t *pl = codes + w * cs;
+        const uint32_t cw = pl[gj];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) cnt[v] += code_count<REP>(pl[gi[v]], cw);
+    }
+}
+__device__ __forceinline__ void gen_rows4(const GenCtx &g, const uint32_t *codes, int cs, const int (&gi)[4], int gj, double (&out)[4]) {
+    uint32_t cnt[4] = {0, 0, 0, 0};
+    if (g.rep == REP_BITS)
+        gen_counts4<REP_BITS>(codes, cs, g.nW, gi, gj, cnt);
+    else if (g.rep == REP_BYTES7)
+        gen_counts4<REP_BYTES7>(codes, cs, g.nW, gi, gj, cnt);
+    else
+        gen_counts4<REP_BYTES8>(codes, cs, g.nW, gi, gj, cnt);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        double val;
+        if (gi[v] < g.N && gj < g.N) {
+            const int agree = g.rep == REP_BITS ? (int)cnt[v] : g.m - (int)cnt[v];
+            val = g.inv_m * (double)agree;
+            if (g.has_shift) val = val - g.sh;
+            if (g.has_scale) val = g.sc * val;
+            if (gi[v] == gj) val = val + g.jitter;
+        } else {
+            val = gi[v] == gj ? 1.0 : 0.0;  // identity padding
+        }
+        out[v] = val;
+    }
 }
 
 // codes != nullptr (one-block-row sweeps): the tile is generated from the leaf codes in LDS instead of read from `tile`.
+// goff: index of the tile's first point (ONE: 0; the second block of TWO: 128), cs: points per code plane.
 template <int W, bool ONE>
 __device__ __forceinline__ void diag_update(const double *__restrict__ tile, long ld, const double *__restrict__ panel0,
                                             int nkb, double *lds, double *S, int lane, int lr, int lk, const Mats &p, int b,
-                                            int rep, const uint32_t *codes) {
+                                            int rep, const uint32_t *codes, int cs = NB, int goff = 0) {
     using T = UpperBlocks<W>;
     double pre[9][4];
+    GenCtx g = {};
+    if (ONE) g = gen_ctx(p, b, rep);
 #pragma unroll
-    for (int i = 0; i < 9; ++i)
+    for (int i = 0; i < 9; ++i) {
+        if (ONE) {
+            const int r0 = goff + T::rb[i] * 16 + lk;
+            const int gi[4] = {r0, r0 + 4, r0 + 8, r0 + 12};
+            gen_rows4(g, codes, cs, gi, goff + T::cb[i] * 16 + lr, pre[i]);
+        } else {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int r = T::rb[i] * 16 + lk + 4 * v, c = T::cb[i] * 16 + lr;
-            pre[i][v] = ONE ? gen_entry(p, b, rep, codes, r, c) : tile[(size_t)r * ld + c];
+            for (int v = 0; v < 4; ++v) pre[i][v] = tile[(size_t)(T::rb[i] * 16 + lk + 4 * v) * ld + T::cb[i] * 16 + lr];
         }
+    }
     f64x4 acc[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
@@ -736,13 +796,13 @@ __device__ __forceinline__ f64x4 x_entry(f64x4 (&xt)[L], f64x4 &tacc, int rb, in
 // Trailing update inside diag_kernel: D[rb,cb] -= U[kb,rb]' U[kb,cb] for Q blocks of a wave's list (entries i0, i0 + 3, ... of
 // the row-major list of the trailing sub-blocks after (kb+1, kb+1); n = trailing block rows): Q independent MFMA chains
 // interleaved, the destination blocks requested before the products.
-template <int Q>
+template <int Q, int STRIDE = 3>  // STRIDE: waves that share the list (3 of 4, or 7 of 8: factor_tile8)
 __device__ __forceinline__ void c_group(double *S, int kb, int n, int i0, int lr, int lk) {
     const double *a[Q], *b[Q];
     double *dd[Q];
 #pragma unroll
     for (int qq = 0; qq < Q; ++qq) {
-        int r = 0, rem = i0 + 3 * qq + 1;  // + 1: the list starts after (kb+1, kb+1)
+        int r = 0, rem = i0 + STRIDE * qq + 1;  // + 1: the list starts after (kb+1, kb+1)
         while (rem >= n - r) {
             rem -= n - r;
             ++r;
@@ -789,65 +849,60 @@ __device__ __forceinline__ void c_group(double *S, int kb, int n, int i0, int lr
 // is enqueued before the diag_kernel it waits for, and the rows a diag_kernel waits for are enqueued after it.
 // ONE: the one-launch evaluation of matrices of one block row (OneBlock; j == 0, nkb == 0) — an instantiation of its
 // own, so that the regular kernel carries none of its code (with a run-time switch diag_kernel ran 52 -> 60 us).
+// TWO (MODE 2, round 5): matrices of TWO block rows (128 < N <= 256 — BO with a couple of hundred points), the whole
+// evaluation in one launch like ONE: block 0 is generated and factored as in ONE; then U_01 = W_0' A_01 with A_01 generated
+// on the fly as the MFMA B operand (W_0 is still in the factor image; the product goes to the matrix's tile (0,1) in the
+// workspace, L2-resident scratch), y_1 -= U_01' z_0 from the accumulators; then block 1 = A_11 (generated) - U_01' U_01 by the
+// rank-128 update of the regular kernel, factored, and the MLL written.  Seven launches (walk, Gram tile, right-hand side,
+// diag, rows, solve, diag) -> walk + this one: N = 256 x 256 forests 0.157 -> see profiles/r05/small_n.txt.
+__device__ __forceinline__ void two_block_offdiag(const Mats &p, int b, int rep, const uint32_t *codes, const double *S,
+                                                  const double *z0, double *__restrict__ U01, double *ysub, int ct0, int nct, int lr,
+                                                  int lk) {
+    const GenCtx g = gen_ctx(p, b, rep);
+#pragma unroll 1
+    for (int ct = ct0; ct < ct0 + nct; ++ct) {  // this wave's 16-column tiles of U_01 (two with four waves, one with eight)
+        f64x4 acc[NSB];
+#pragma unroll
+        for (int rt = 0; rt < NSB; ++rt) acc[rt] = (f64x4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+        for (int kt = 0; kt < NSB; ++kt) {  // k ascending for every element; W_0 is upper triangular: row tiles rt >= kt only
+            double bv[4];  // B fragments of the k-tile: A_01[kt * 16 + kk * 4 + lk][ct * 16 + lr], kk = 0..3
+            {
+                const int r0 = kt * SB + lk;
+                const int gi[4] = {r0, r0 + 4, r0 + 8, r0 + 12};
+                gen_rows4(g, codes, 2 * NB, gi, NB + ct * SB + lr, bv);
+            }
+#pragma unroll
+            for (int rt = 0; rt < NSB; ++rt) {
+                if (rt >= kt) {  // wave-uniform (MFMA ignores EXEC: a scalar branch)
+                    const double *wb = S + blk_off(kt, rt);
+#pragma unroll
+                    for (int kk = 0; kk < SB / 4; ++kk)
+                        acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(wb[(kk * 4 + lk) * SB + lr], bv[kk], acc[rt], 0, 0, 0);
+                }
+            }
+        }
+        double sum = 0.0;
+#pragma unroll
+        for (int rt = 0; rt < NSB; ++rt)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int r = rt * SB + lk + 4 * v;
+                U01[(size_t)r * p.ld + ct * SB + lr] = acc[rt][v];
+                sum = fma(acc[rt][v], z0[r], sum);
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        if (lk == 0) ysub[ct * SB + lr] = sum;
+    }
+}
+
+// The blocked Cholesky + inverse of the tile in the factor image S (diag_kernel's middle; also the two blocks of two_block_kernel).
+// copy_only: diag_copy has eliminated sub-block (0,0) already.  nsb: live 16-wide sub-blocks (ONE: the rest is identity padding).
+// Out: S = the inverse W (upper block triangle), logsum / bad in wave 0.
 template <bool ONE>
-__global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb, int want_g, int wait_slot, int wait_value, OneBlock ob,
-                                                          int publish) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int tid = threadIdx.x, b = blockIdx.x;
-    const Lane q = lane_of(tid);
-    const int wave = tid >> 6, lane = tid & 63;
-    double *Ab = p.A + (size_t)b * p.bstride;
-    double *tile = Ab + (size_t)j * NB * p.ld + (size_t)j * NB;
-    // operands of the kernel's last phase, requested now so their latency hides behind the factorisation
-    // (solve_kernel(j-1) finished updating y_j before this launch)
-    if (publish && b == 0 && tid == 0 && p.sync)  // this launch has started: everything before it on this stream is done
-        __hip_atomic_store(p.sync + 3, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    constexpr bool one = ONE;
-    const double y_in = tid < NB ? (one ? (tid < p.N ? ob.y[tid] : 0.0) : p.yz[(size_t)b * p.nrb * NB + (size_t)j * NB + tid]) : 0.0;
-    const double acc_quad = (tid == 0 && !one) ? p.accum[(size_t)b * 2 + 0] : 0.0;
-    const double acc_logdet = (tid == 0 && !one) ? p.accum[(size_t)b * 2 + 1] : 0.0;
-    const int info_in = (tid == 0 && !one) ? p.info[b] : 0;
-
-    double *S = lds;                                          // packed upper block triangle, NBLK x [16][16]
-    double *vec = lds + NBLK * SB * SB;                       // [2][128] y | upper-half partial sums
-    double *red = vec + 2 * NB;                               // [8]
-    uint32_t *codes = nullptr;
-    if (one) {  // the matrix's leaf codes (nW x 128 dwords) behind everything else in LDS
-        codes = reinterpret_cast<uint32_t *>(red + 8);
-        const uint32_t *lb = p.leafx + (size_t)b * p.nW * NB;  // npad == 128
-        for (int e = tid; e < p.nW * NB; e += THREADS) codes[e] = lb[e];
-        __syncthreads();
-    }
-    double logsum = 0.0;  // sum of log(pivot) / 2 ... (wave 0; pivots_logsum in the last sub-block step)
-    double pacc = 1.0;    // ... from factor16's pivot products
-    int bad = 0;
-    const bool copy_only = !ONE && nkb == 0;  // workgroup-uniform
-    if (copy_only) {
-        const int wsel = __builtin_amdgcn_readfirstlane(wave);
-        if (wsel == 0)
-            diag_copy<0>(tile, p.ld, S, lane, q.lr, q.lk, pacc, bad);
-        else if (wsel == 1)
-            diag_copy<1>(tile, p.ld, S, lane, q.lr, q.lk, pacc, bad);
-        else if (wsel == 2)
-            diag_copy<2>(tile, p.ld, S, lane, q.lr, q.lk, pacc, bad);
-        else
-            diag_copy<3>(tile, p.ld, S, lane, q.lr, q.lk, pacc, bad);
-    } else {
-        // D = P - sum_k U[k,j]'U[k,j] on the upper block triangle (the product stages alias S: the update's last barrier
-        // precedes the writes of S)
-        const double *prev = Ab + (size_t)(j - nkb) * NB * p.ld + (size_t)j * NB;  // U[j-nkb, j]
-        const int wsel = __builtin_amdgcn_readfirstlane(wave);
-        if (wsel == 0)
-            diag_update<0, ONE>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk, p, b, ob.rep, codes);
-        else if (wsel == 1)
-            diag_update<1, ONE>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk, p, b, ob.rep, codes);
-        else if (wsel == 2)
-            diag_update<2, ONE>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk, p, b, ob.rep, codes);
-        else
-            diag_update<3, ONE>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk, p, b, ob.rep, codes);
-    }
-    __syncthreads();
-
+__device__ __forceinline__ void factor_tile(double *S, int nsb, bool copy_only, int wave_u, int lane, int lr, int lk, double &logsum,
+                                            double &pacc, int &bad) {
     // --- blocked Cholesky D = U'U and X = U^-1, software-pipelined over the four waves ------------------------------
     // The serial part is the eight 16x16 eliminations (factor16, one wave, ~3.8 K cycles each; 6.0 K before round 4's MFMA form).  Wave 0 runs that
     // chain: in step kb it updates only the NEXT diagonal sub-block with row kb and factors it, while waves 1-3 do the
@@ -860,8 +915,6 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
     // A wave owns whole ROWS of X and keeps their blocks in registers (x_entry); a column of X goes to the packed image one
     // step after it was computed, when nobody reads the U blocks it replaces any more.
     // Same MFMA chain per element as the unpipelined order: identical results.
-    const int lr = q.lr, lk = q.lk;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     // rows of X owned by this wave (-1: none).  Full tiles: {0,5}, {1,4}, {2,3} for waves 1-3 (7 + 2, 6 + 3, 5 + 4 block products
     // in the last step, the longest) and row 6 — one product, in the last step, when wave 0 has no elimination left — for
     // wave 0.  One-block-row matrices (any number of live sub-blocks): {0,6}, {1,4}, {2,3,5}, none for wave 0.
@@ -872,9 +925,6 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
         if (wave_u == 0) factor16(S + blk_off(0, 0), lane, 0, pacc, bad);
         __syncthreads();
     }
-    // one-block-row matrices of fewer than 113 points: the sub-blocks beyond the last live one are identity padding — their
-    // factor, their inverse and their share of log|D| are what the tile generation left there, nothing to compute
-    const int nsb = one ? (p.N + SB - 1) / SB : NSB;
     auto phase_b = [&](int kb, double *dblk) {  // (B) U[kb,cb] = W_kk' D[kb,cb]
         for (int cb = kb + 1 + wave_u; cb < nsb; cb += 4) {
             double *blk = S + blk_off(kb, cb);
@@ -890,8 +940,10 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
         f64x4 xw[2], tw;  // row nsb - 2 of X from the diagonal on (full tiles only)
         for (int kb = 0; kb < nsb; ++kb) {
             double *dblk = S + blk_off(kb, kb);  // W_kk
+            DIAG_STAMP(8 + kb);
             phase_b(kb, dblk);
             __syncthreads();
+            DIAG_STAMP(16 + kb);
             if (kb + 1 < nsb) {
                 const double *urow = S + blk_off(kb, kb + 1);
                 double *dst = S + blk_off(kb + 1, kb + 1);
@@ -902,6 +954,7 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 factor16(dst, lane, (kb + 1) * SB, pacc, bad);
+                DIAG_STAMP(24 + kb);
             } else {  // last step: nothing left to eliminate — the one entry of X's row 6, and the logs of all the pivots (this
                       // wave used to wait ~3 K cycles for the others here)
                 if (!ONE) pend[0] = x_entry(xw, tw, xrow[0], kb, nsb, S, dblk, lr, lk);
@@ -957,14 +1010,183 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
     }
     __syncthreads();
 
+}
+
+// factor_tile with EIGHT waves (round 5; chain-bound launches: a lone / few matrices, the one-launch kernels of small N).  Since
+// round 4's MFMA form of factor16 (6.0 K -> 4.1 K cycles per sub-block step) the three helper waves bound most steps of the
+// four-wave form — wave 0 waited 0.4-2.0 K cycles per step, 4 K in the last, for their trailing updates and inverse columns
+// (profiles/r05/diag_waves.txt).  Here SIX helpers do that work — waves 1-3 and 5-7, two on each of SIMDs 1-3 — and wave 4 only
+// keeps the barriers' count: it shares SIMD 0 with wave 0, and with work of its own it stretched the elimination chain from 4.1 K
+// to 4.7-5.8 K cycles per step (same file), which ate what the helpers had gained.  A helper owns one row of X (the sixth: rows 5
+// and 6), the trailing blocks go round the six, phase (B) round the seven working waves.  Same blocks, same MFMA chain per
+// element, same two barriers per step: identical bits.  Not for launches that share CUs with row workgroups.
+template <bool ONE>
+__device__ __forceinline__ void factor_tile8(double *S, int nsb, bool copy_only, int wave_u, int lane, int lr, int lk, double &logsum,
+                                             double &pacc, int &bad) {
+    const int bw = wave_u < 4 ? wave_u : wave_u - 1;  // phase (B): index among the seven working waves (wave 4: none)
+    const int h = wave_u < 4 ? wave_u - 1 : wave_u - 2;  // helper index 0..5 (waves 1-3, 5-7)
+    const int xr = h;                                    // the row of X a helper owns; helper 5 owns row 6 as well
+    f64x4 pend, pend6;  // column kb of the owned row(s) (transposed, see x_entry), stored at the start of the next step
+    if (!copy_only) {
+        if (wave_u == 0) factor16(S + blk_off(0, 0), lane, 0, pacc, bad);
+        __syncthreads();
+    }
+    auto phase_b = [&](int kb, double *dblk) {  // (B) U[kb,cb] = W_kk' D[kb,cb]: at most one block per working wave
+        const int cb = kb + 1 + bw;
+        if (cb < nsb) {
+            double *blk = S + blk_off(kb, cb);
+            f64x4 u = {0.0, 0.0, 0.0, 0.0};
+            mfma_tn(u, dblk, SB, blk, SB, lr, lk);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) blk[(lk + 4 * v) * SB + lr] = u[v];
+        }
+    };
+    if (wave_u == 0) {
+        for (int kb = 0; kb < nsb; ++kb) {
+            double *dblk = S + blk_off(kb, kb);  // W_kk
+            DIAG_STAMP(8 + kb);
+            phase_b(kb, dblk);
+            __syncthreads();
+            DIAG_STAMP(16 + kb);
+            if (kb + 1 < nsb) {
+                const double *urow = S + blk_off(kb, kb + 1);
+                double *dst = S + blk_off(kb + 1, kb + 1);
+                f64x4 u = {0.0, 0.0, 0.0, 0.0};
+                mfma_tn(u, urow, SB, urow, SB, lr, lk);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) dst[(lk + 4 * v) * SB + lr] -= u[v];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                factor16(dst, lane, (kb + 1) * SB, pacc, bad);
+                DIAG_STAMP(24 + kb);
+            } else {
+                logsum = pivots_logsum(pacc);
+            }
+            __syncthreads();
+        }
+    } else if (wave_u == 4) {  // SIMD 0 belongs to the elimination chain
+        for (int kb = 0; kb < nsb; ++kb) {
+            __syncthreads();
+            __syncthreads();
+        }
+    } else {
+        f64x4 xt[7], ta;       // the owned row's blocks from the diagonal on, and its next column's sum so far
+        f64x4 xt6[1], ta6;     // helper 5: the same for row 6
+        auto store_col = [&](int row, int col, const f64x4 &pe) {
+            double *dst = S + blk_off(row, col);
+            const f64x4 xs = frag_transpose(pe, lr, lk);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) dst[(lk + 4 * v) * SB + lr] = xs[v];
+        };
+        for (int kb = 0; kb < nsb; ++kb) {
+            double *dblk = S + blk_off(kb, kb);  // W_kk
+            phase_b(kb, dblk);
+            __syncthreads();
+            if (kb >= 2 && xr < kb - 1) store_col(xr, kb - 1, pend);  // column kb-1 of X, computed in the previous step
+            // (row 6 has its only entry in the last step: stored after the loop)
+            {  // (C), all but the next diagonal sub-block: block p of the row-major list goes to helper p % 6
+                const int n = nsb - 1 - kb, total = n * (n + 1) / 2 - 1;
+                int i0 = h;
+                for (; i0 + 12 < total; i0 += 18) c_group<3, 6>(S, kb, n, i0, lr, lk);
+                if (i0 + 6 < total)
+                    c_group<2, 6>(S, kb, n, i0, lr, lk);
+                else if (i0 < total)
+                    c_group<1, 6>(S, kb, n, i0, lr, lk);
+            }
+            if (kb >= 1 && xr < kb) pend = x_entry(xt, ta, xr, kb, nsb, S, dblk, lr, lk);
+            if (h == 5 && kb == 7) pend6 = x_entry(xt6, ta6, 6, kb, nsb, S, dblk, lr, lk);  // (wave-uniform)
+            __syncthreads();
+        }
+        if (xr < nsb - 1) store_col(xr, nsb - 1, pend);  // last column of X
+        if (h == 5 && nsb == NSB) store_col(6, 7, pend6);
+    }
+    __syncthreads();
+}
+
+// NW: waves per workgroup — 4, or 8 for chain-bound launches (factor_tile8; the phases around the factorisation stay with the
+// first four waves, the others only keep the barriers' count).
+template <bool ONE, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void diag_kernel(Mats p, int j, int nkb, int want_g, int wait_slot, int wait_value, OneBlock ob,
+                                                          int publish) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const Lane q = lane_of(tid);
+    const int wave = tid >> 6, lane = tid & 63;
+    double *Ab = p.A + (size_t)b * p.bstride;
+    double *tile = Ab + (size_t)j * NB * p.ld + (size_t)j * NB;
+    // operands of the kernel's last phase, requested now so their latency hides behind the factorisation
+    // (solve_kernel(j-1) finished updating y_j before this launch)
+    if (publish && b == 0 && tid == 0 && p.sync)  // this launch has started: everything before it on this stream is done
+        __hip_atomic_store(p.sync + 3, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    constexpr bool one = ONE;
+    const double y_in = tid < NB ? (one ? (tid < p.N ? ob.y[tid] : 0.0) : p.yz[(size_t)b * p.nrb * NB + (size_t)j * NB + tid]) : 0.0;
+    const double acc_quad = (tid == 0 && !one) ? p.accum[(size_t)b * 2 + 0] : 0.0;
+    const double acc_logdet = (tid == 0 && !one) ? p.accum[(size_t)b * 2 + 1] : 0.0;
+    const int info_in = (tid == 0 && !one) ? p.info[b] : 0;
+    DIAG_STAMP(0);
+
+    double *S = lds;                                          // packed upper block triangle, NBLK x [16][16]
+    double *vec = lds + NBLK * SB * SB;                       // [2][128] y | upper-half partial sums
+    double *red = vec + 2 * NB;                               // [8]
+    uint32_t *codes = nullptr;
+    if (one) {  // the matrix's leaf codes (nW x 128 dwords) behind everything else in LDS
+        codes = reinterpret_cast<uint32_t *>(red + 8);
+        const uint32_t *lb = p.leafx + (size_t)b * p.nW * NB;  // npad == 128
+        for (int e = tid; e < p.nW * NB; e += NW * 64) codes[e] = lb[e];
+        __syncthreads();
+    }
+    double logsum = 0.0;  // sum of log(pivot) / 2 ... (wave 0; pivots_logsum in the last sub-block step)
+    double pacc = 1.0;    // ... from factor16's pivot products
+    int bad = 0;
+    const bool copy_only = !ONE && nkb == 0;  // workgroup-uniform
+    if (copy_only) {
+        const int wsel = __builtin_amdgcn_readfirstlane(wave);
+        if (wsel == 0)
+            diag_copy<0>(tile, p.ld, S, lane, q.lr, q.lk, pacc, bad);
+        else if (wsel == 1)
+            diag_copy<1>(tile, p.ld, S, lane, q.lr, q.lk, pacc, bad);
+        else if (wsel == 2)
+            diag_copy<2>(tile, p.ld, S, lane, q.lr, q.lk, pacc, bad);
+        else if (NW == 4 || wsel == 3)
+            diag_copy<3>(tile, p.ld, S, lane, q.lr, q.lk, pacc, bad);
+    } else {
+        // D = P - sum_k U[k,j]'U[k,j] on the upper block triangle (the product stages alias S: the update's last barrier
+        // precedes the writes of S)
+        const double *prev = Ab + (size_t)(j - nkb) * NB * p.ld + (size_t)j * NB;  // U[j-nkb, j]
+        const int wsel = __builtin_amdgcn_readfirstlane(wave);
+        if (wsel == 0)
+            diag_update<0, ONE>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk, p, b, ob.rep, codes);
+        else if (wsel == 1)
+            diag_update<1, ONE>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk, p, b, ob.rep, codes);
+        else if (wsel == 2)
+            diag_update<2, ONE>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk, p, b, ob.rep, codes);
+        else if (NW == 4 || wsel == 3)
+            diag_update<3, ONE>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk, p, b, ob.rep, codes);
+        else  // waves 4-7: the barriers of the update's product loops (diag_update: 1 + 8 per block row applied, two at most)
+            for (int a = (nkb > 1 ? 2 : nkb) * (1 + NB / BK); a > 0; --a) __syncthreads();
+    }
+    __syncthreads();
+
+    const int lr = q.lr, lk = q.lk;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // one-block-row matrices of fewer than 113 points: the sub-blocks beyond the last live one are identity padding — their
+    // factor, their inverse and their share of log|D| are what the tile generation left there, nothing to compute
+    const int nsb = one ? (p.N + SB - 1) / SB : NSB;
+    DIAG_STAMP(1);
+    if (NW == 8)
+        factor_tile8<ONE>(S, nsb, copy_only, wave_u, lane, lr, lk, logsum, pacc, bad);
+    else
+        factor_tile<ONE>(S, nsb, copy_only, wave_u, lane, lr, lk, logsum, pacc, bad);
+    DIAG_STAMP(2);
+
     // --- W_j out, sub-block by sub-block (explicit zeros below the block diagonal: solve_kernel multiplies the full
     // tile; the diagonal sub-blocks are upper triangular with exact zeros already) --------------------------------
     double *Wb = w_block(p, b);
-    if (!one) {  // (nobody reads W_0 of a one-block-row matrix)
+    auto write_w = [&](int t) {  // t: 0 .. 255
         // the 36 sub-blocks on or above the block diagonal only: every consumer skips the k-tiles below it (gemm_upper_tri,
         // solve_narrow_kernel, solve_direct_kernel), so what the buffer holds there never reaches an MFMA.  Two doubles per
-        // thread, the two halves of the workgroup on alternate sub-blocks.
-        const int half = __builtin_amdgcn_readfirstlane(tid >> 7), e = 2 * (tid & 127), r = e >> 4, c = e & 15;
+        // thread, the two halves of the 256 threads on alternate sub-blocks.
+        const int half = __builtin_amdgcn_readfirstlane(t >> 7), e = 2 * (t & 127), r = e >> 4, c = e & 15;
         int cnt = 0;
 #pragma unroll
         for (int rbk = 0; rbk < NSB; ++rbk)
@@ -973,11 +1195,16 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
                 if ((cnt & 1) == half)
                     *reinterpret_cast<f64x2 *>(Wb + (size_t)(rbk * SB + r) * NB + cbk * SB + c) =
                         *reinterpret_cast<const f64x2 *>(S + blk_off(rbk, cbk) + e);
-    }
+    };
+    // (nobody reads W_0 of a one-block-row matrix.)  Eight waves: waves 4-7 write W_j at the very end, beside the first four
+    // waves' z_j — they only pass the barriers of that phase first.
+    if (!one && NW == 4) write_w(tid);
 
-    if (want_g)  // workgroup-uniform
+    DIAG_STAMP(3);
+    if (want_g && (NW == 4 || wave_u < 4))  // workgroup-uniform (wave-uniform with eight waves: no barrier inside)
         diag_g(Ab + (size_t)(j - 1) * NB * p.ld + (size_t)j * NB, p.ld, S, p.W + (size_t)b * W_STRIDE, wave_u, lr, lk);
 
+    DIAG_STAMP(4);
     // --- z_j = W_j' y_j ; quad += |z_j|^2 ; logdet += 2 sum log u_kk ----------------------------
     // thread (c, half) sums the sub-block rows 4*half .. 4*half+3 of column c (only sub-blocks on or above the block
     // diagonal exist: W_j is upper triangular).  y_j and the accumulators were loaded at kernel entry.
@@ -985,18 +1212,18 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
     if (tid < NB) vec[tid] = y_in;
     __syncthreads();
     {
-        const int c = tid & (NB - 1), half = tid >> 7, cbk = c >> 4, cc = c & 15;
+        const int c = tid & (NB - 1), half = tid >> 7, cbk = c >> 4, cc = c & 15;  // (eight waves: half = 2, 3 do nothing)
         double part = 0.0;
 #pragma unroll
         for (int i = 0; i < NSB / 2; ++i) {
             const int rbk = half * (NSB / 2) + i;
-            if (rbk <= cbk) {
+            if (rbk <= cbk && (NW == 4 || half < 2)) {
                 const double *col = S + blk_off(rbk, cbk) + cc;
 #pragma unroll
                 for (int rr = 0; rr < SB; ++rr) part = fma(col[rr * SB], vec[rbk * SB + rr], part);
             }
         }
-        if (half) vec[NB + c] = part;  // vec has 2 * NB doubles
+        if (half == 1) vec[NB + c] = part;  // vec has 2 * NB doubles
         __syncthreads();
         double zz = 0.0;
         if (!half) {
@@ -1009,6 +1236,8 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
         if (lane == 0) red[wave] = zz;
     }
     __syncthreads();
+    DIAG_STAMP(5);
+    if (!one && NW == 8 && tid >= THREADS) write_w(tid - THREADS);
     if (tid == 0 && one) {  // finish_mll_kernel's arithmetic (quick_inverse.py:38 / mcmc_record_mll.py:73)
         double v = -(red[0] + red[1]) - 2.0 * logsum;
         if (ob.include_2pi) v = v - (double)p.N * log(2.0 * M_PI);
@@ -1049,6 +1278,118 @@ __global__ __launch_bounds__(THREADS, 2) void diag_kernel(Mats p, int j, int nkb
             if (ob.include_2pi) v = v - (double)p.N * log(2.0 * M_PI);
             ob.mll[b] = 0.5 * v;
         }
+    }
+}
+
+// two_block_kernel (round 5): matrices of TWO block rows (128 < N <= 256 — BO with a couple of hundred points), the whole
+// evaluation in one launch, as diag_kernel<true> does it for one block row: block 0 is generated and factored; then
+// U_01 = W_0' A_01 with A_01 generated on the fly as the MFMA B operand (two_block_offdiag: W_0 is still in the factor image; the
+// product goes to the matrix's tile (0,1) of the workspace — L2-resident scratch — and y_1 -= U_01' z_0 comes from the
+// accumulators); then block 1 = A_11 (generated) - U_01' U_01 by the regular rank-128 update (diag_update), factored, and
+// the MLL written.  Seven launches (leaf walk, Gram tile, right-hand side, diag, rows, solve, diag) become two.  A kernel of
+// its own, not a third mode of diag_kernel: wrapping that kernel's body in a loop over the blocks took the regular
+// instantiation from 223 VGPRs to 256 with scratch.
+#ifdef BARK_TWO_STAMPS
+__device__ unsigned long long g_two_stamps[16];
+#endif
+template <int NW>  // waves per workgroup: 4, or 8 (factor_tile8) while a chunk has a CU per matrix
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void two_block_kernel(Mats p, OneBlock ob) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const Lane q = lane_of(tid);
+    const int wave = tid >> 6, lane = tid & 63, lr = q.lr, lk = q.lk;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    double *Ab = p.A + (size_t)b * p.bstride;
+    double *S = lds;                      // packed upper block triangle, NBLK x [16][16]
+    double *vec = lds + NBLK * SB * SB;   // [2][128] y | upper-half partial sums
+    double *red = vec + 2 * NB;           // [8]
+    constexpr int CS = 2 * NB;            // points per code plane
+    uint32_t *codes = reinterpret_cast<uint32_t *>(red + 8);          // [nW][256]
+    double *zsave = reinterpret_cast<double *>(codes + p.nW * CS);    // z_0
+    double *ysub = zsave + NB;                                        // U_01' z_0
+    {
+        const uint32_t *lb = p.leafx + (size_t)b * p.nW * CS;  // npad == 256
+        for (int e = tid; e < p.nW * CS; e += NW * 64) codes[e] = lb[e];
+    }
+    double y_in = tid < NB ? ob.y[tid] : 0.0;  // N > 128
+    __syncthreads();
+    double quad_sum = 0.0, logsum_sum = 0.0;  // over the two blocks (thread 0: wave 0 ran factor16)
+    int bad_all = 0;
+#ifdef BARK_TWO_STAMPS
+    int stamp_n = 0;
+#define TWO_STAMP() do { if (tid == 0 && b == 0) g_two_stamps[stamp_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TWO_STAMP() do {} while (0)
+#endif
+    TWO_STAMP();
+    auto block = [&](auto BLK) {
+        constexpr int blk = decltype(BLK)::value;
+        double logsum = 0.0, pacc = 1.0;
+        int bad = 0;
+        if (wave_u == 0)
+            diag_update<0, true>(nullptr, p.ld, Ab + NB, blk, lds, S, lane, lr, lk, p, b, ob.rep, codes, CS, blk * NB);
+        else if (wave_u == 1)
+            diag_update<1, true>(nullptr, p.ld, Ab + NB, blk, lds, S, lane, lr, lk, p, b, ob.rep, codes, CS, blk * NB);
+        else if (wave_u == 2)
+            diag_update<2, true>(nullptr, p.ld, Ab + NB, blk, lds, S, lane, lr, lk, p, b, ob.rep, codes, CS, blk * NB);
+        else if (NW == 4 || wave_u == 3)
+            diag_update<3, true>(nullptr, p.ld, Ab + NB, blk, lds, S, lane, lr, lk, p, b, ob.rep, codes, CS, blk * NB);
+        else  // waves 4-7: the barriers of the update's product loop (diag_update: 1 + 8 for the one block row of the second block)
+            for (int a = blk * (1 + NB / BK); a > 0; --a) __syncthreads();
+        __syncthreads();
+        TWO_STAMP();
+        const int nsb = blk == 0 ? NSB : (p.N - NB + SB - 1) / SB;  // the second block's live sub-blocks; the rest is identity padding
+        if (NW == 8)
+            factor_tile8<true>(S, nsb, false, wave_u, lane, lr, lk, logsum, pacc, bad);
+        else
+            factor_tile<true>(S, nsb, false, wave_u, lane, lr, lk, logsum, pacc, bad);
+        TWO_STAMP();
+        // z = W' y ; |z|^2 (diag_kernel's last phase)
+        if (tid < NB) vec[tid] = y_in;
+        __syncthreads();
+        {
+            const int c = tid & (NB - 1), half = tid >> 7, cbk = c >> 4, cc = c & 15;  // (eight waves: half = 2, 3 do nothing)
+            double part = 0.0;
+#pragma unroll
+            for (int i = 0; i < NSB / 2; ++i) {
+                const int rbk = half * (NSB / 2) + i;
+                if (rbk <= cbk && (NW == 4 || half < 2)) {
+                    const double *col = S + blk_off(rbk, cbk) + cc;
+#pragma unroll
+                    for (int rr = 0; rr < SB; ++rr) part = fma(col[rr * SB], vec[rbk * SB + rr], part);
+                }
+            }
+            if (half == 1) vec[NB + c] = part;
+            __syncthreads();
+            double zz = 0.0;
+            if (!half) {
+                const double z = part + vec[NB + c];
+                zsave[c] = z;
+                zz = z * z;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) zz += __shfl_xor(zz, off);
+            if (lane == 0) red[wave] = zz;
+        }
+        __syncthreads();
+        quad_sum += red[0] + red[1];
+        logsum_sum += logsum;
+        bad_all = (bad && !bad_all) ? blk * NB + bad : bad_all;
+        TWO_STAMP();
+        if (blk == 0) {
+            two_block_offdiag(p, b, ob.rep, codes, S, zsave, Ab + NB, ysub, NW == 8 ? wave_u : 2 * wave_u, NW == 8 ? 1 : 2, lr, lk);
+            __syncthreads();  // U_01 (global: this workgroup's own stores) and ysub are visible to every wave
+            TWO_STAMP();
+            y_in = tid < NB ? ((NB + tid < p.N ? ob.y[NB + tid] : 0.0) - ysub[tid]) : 0.0;
+        }
+    };
+    block(std::integral_constant<int, 0>{});
+    block(std::integral_constant<int, 1>{});
+    if (tid == 0) {  // finish_mll_kernel's arithmetic (quick_inverse.py:38 / mcmc_record_mll.py:73)
+        double v = -quad_sum - 2.0 * logsum_sum;
+        if (ob.include_2pi) v = v - (double)p.N * log(2.0 * M_PI);
+        ob.mll[b] = 0.5 * v;
+        p.info[b] = *ob.fault ? -1 : bad_all;
     }
 }
 
@@ -1865,6 +2206,24 @@ constexpr size_t SLAB_SET_TILES = (LA_SLOTS > SPLITK_SLOTS ? LA_SLOTS : SPLITK_S
 #define BARK_LA_MIN_WORK 450
 #endif
 constexpr long LA_MIN_WORK = BARK_LA_MIN_WORK;
+// Critical-path split (the plain split of an under-filled step: lone and few matrices): up to SPLIT_FINE slabs per block row of the
+// K range, while the launch stays within SPLIT_FINE_MAX_WGS workgroups.  A split workgroup on an idle chip is a chain of DMA round
+// trips (~2.7 us per 16-row k-tile, 8 per block row: 22 us for the one block row of a slab), and since round 5's eight-wave
+// diag_kernel that chain — not the diagonal factor beside it — bounds the block step of a lone matrix of a few block rows; halving
+// it costs a second slab per block row in the reduce launch.  Round 5, same box, one process per variant, ms (1 | 2 slabs per block
+// row up to 256 workgroups | ... up to 384 | 3 slabs up to 256): N = 1024 x 1 0.371 | 0.358 | 0.357 | 0.359, N = 2048 x 1 0.762 | 0.693 |
+// 0.695 | 0.713, N = 1500 x 1 0.568 | 0.536 | 0.537 | 0.536, N = 3000 x 1 1.170 | 1.128 | 1.156 | 1.147, N = 4096 x 1 1.696 | 1.668 | 1.694 | 1.682,
+// N = 1024 x 4 0.391 | 0.368 | 0.370 | 0.368, x 8 0.420 | 0.398 | 0.403 | 0.413, N = 2048 x 4 0.923 | 0.913 | 0.923 | 0.923; without the
+// workgroup bound (4 slabs, or 2 everywhere) N = 4096 x 1 lost 8 % and N = 2048 x 4 5 % to the longer reduce
+// (profiles/r05/chain_bound_levers.txt item 4; round 4 had measured the finer slabs beside the four-wave diag_kernel: nothing).
+#ifndef BARK_SPLIT_FINE
+#define BARK_SPLIT_FINE 2
+#endif
+constexpr int SPLIT_FINE = BARK_SPLIT_FINE;
+#ifndef BARK_SPLIT_FINE_MAX_WGS
+#define BARK_SPLIT_FINE_MAX_WGS 256
+#endif
+constexpr long SPLIT_FINE_MAX_WGS = BARK_SPLIT_FINE_MAX_WGS;  // ... while the launch stays within this many workgroups (more slabs cost more in the reduce launch than they save)
 #ifndef BARK_TAIL_MAX_WGS
 #define BARK_TAIL_MAX_WGS 192
 #endif
@@ -1891,6 +2250,15 @@ constexpr int SPLITK_LAYOUT_MAX_TILES = BARK_SPLITK_LAYOUT_MAX_TILES;
 constexpr int64_t SPLITK_LAYOUT_MAX_WORK = BARK_SPLITK_LAYOUT_MAX_WORK;
 // Build-time tuning constants of the pipelined schedule (numbers only: every on/off alternative that was measured and
 // lost is gone from the sources, with its figures left in the comment next to the code that won).
+#ifndef BARK_DIAG_WAVES8
+#define BARK_DIAG_WAVES8 1  // chain-bound diag launches (a CU per matrix) with eight waves: factor_tile8
+#endif
+constexpr int DIAG8_MAX_BC = 256;  // one-launch kernels (N <= 256): eight waves up to this many matrices per chunk
+#ifndef BARK_TWO_BLOCK
+#define BARK_TWO_BLOCK 1  // 128 < N <= 256, MLL only: the one-launch evaluation by two_block_kernel (0: the multi-launch sweep)
+#endif
+// ... for chunks of TWO_MIN_BC .. TWO_MAX_BC matrices, and larger chunks up to TWO_ANY_BC_MAX_N points (plan_chunk has the table)
+constexpr int TWO_MIN_BC = 16, TWO_MAX_BC = 384, TWO_ANY_BC_MAX_N = 224;
 #ifndef BARK_PIPE_MIN_NRB
 #define BARK_PIPE_MIN_NRB 8
 #endif
@@ -2016,8 +2384,12 @@ int set_lds_limits() {
         auto set = [](const void *fn, size_t bytes) {
             return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         };
-        hipError_t e = set(reinterpret_cast<const void *>(diag_kernel<false>), DIAG_LDS_EXCLUSIVE);
-        if (e == hipSuccess) e = set(reinterpret_cast<const void *>(diag_kernel<true>), DIAG_LDS_EXCLUSIVE);
+        hipError_t e = set(reinterpret_cast<const void *>(diag_kernel<false, 4>), DIAG_LDS_EXCLUSIVE);
+        if (e == hipSuccess) e = set(reinterpret_cast<const void *>(diag_kernel<true, 4>), DIAG_LDS_EXCLUSIVE);
+        if (e == hipSuccess) e = set(reinterpret_cast<const void *>(two_block_kernel<4>), DIAG_LDS_EXCLUSIVE);
+        if (e == hipSuccess) e = set(reinterpret_cast<const void *>(two_block_kernel<8>), DIAG_LDS_EXCLUSIVE);
+        if (e == hipSuccess) e = set(reinterpret_cast<const void *>(diag_kernel<false, 8>), DIAG_LDS_EXCLUSIVE);
+        if (e == hipSuccess) e = set(reinterpret_cast<const void *>(diag_kernel<true, 8>), DIAG_LDS_EXCLUSIVE);
         if (e == hipSuccess) e = set(reinterpret_cast<const void *>(row_kernel<0>), GEMM_LDS);
         if (e == hipSuccess) e = set(reinterpret_cast<const void *>(row_kernel<1>), GEMM_LDS);
         if (e == hipSuccess) e = set(reinterpret_cast<const void *>(row_kernel<2>), GEMM_LDS);
@@ -2244,7 +2616,19 @@ struct Sweep {
     int launch_one_block(const double *y, double *mll, const int32_t *fault, int include_2pi) {
         const OneBlock ob{y, mll, fault, include_2pi, rep};
         const size_t lds_bytes = DIAG_LDS + (size_t)p.nW * NB * sizeof(uint32_t);
-        hipLaunchKernelGGL(diag_kernel<true>, dim3((unsigned)p.Bc), dim3(THREADS), lds_bytes, main, p, 0, 0, 0, -2, 0, ob, 0);
+        // eight waves (factor_tile8) while every matrix of the chunk has a CU to itself; beyond that two four-wave workgroups share one
+        const bool w8 = BARK_DIAG_WAVES8 && p.Bc <= DIAG8_MAX_BC;
+        if (nrb == 2) {  // two_block_kernel: codes of 256 points + z_0 + U_01' z_0 behind the factor image
+            const size_t lds2 = DIAG_LDS + (size_t)p.nW * 2 * NB * sizeof(uint32_t) + 2 * NB * sizeof(double);
+            if (w8)
+                hipLaunchKernelGGL(two_block_kernel<8>, dim3((unsigned)p.Bc), dim3(512), lds2, main, p, ob);
+            else
+                hipLaunchKernelGGL(two_block_kernel<4>, dim3((unsigned)p.Bc), dim3(THREADS), lds2, main, p, ob);
+        } else if (w8) {
+            hipLaunchKernelGGL((diag_kernel<true, 8>), dim3((unsigned)p.Bc), dim3(512), lds_bytes, main, p, 0, 0, 0, -2, 0, ob, 0);
+        } else {
+            hipLaunchKernelGGL((diag_kernel<true, 4>), dim3((unsigned)p.Bc), dim3(THREADS), lds_bytes, main, p, 0, 0, 0, -2, 0, ob, 0);
+        }
         BARK_LAUNCH_CHECK();
         return BARK_OK;
     }
@@ -2271,8 +2655,12 @@ struct Sweep {
         // the last block step of an MLL-only sweep also writes the MLL (no row launch left to wait for there: wait_slot < 0)
         const OneBlock fin = (fin_mll && j == nrb_steps - 1 && wait_slot < 0) ? OneBlock{nullptr, fin_mll, fin_fault, fin_2pi, rep} : OneBlock{};
         if (fin.mll) finished = true;
-        hipLaunchKernelGGL(diag_kernel<false>, dim3((unsigned)p.Bc), dim3(THREADS), exclusive ? DIAG_LDS_EXCLUSIVE : DIAG_LDS, main, p, j, nkb,
-                           want_g, wait_slot, wait_value, fin, publish);
+        if (exclusive && BARK_DIAG_WAVES8)  // a CU to itself: eight waves (factor_tile8)
+            hipLaunchKernelGGL((diag_kernel<false, 8>), dim3((unsigned)p.Bc), dim3(512), DIAG_LDS_EXCLUSIVE, main, p, j, nkb, want_g, wait_slot,
+                               wait_value, fin, publish);
+        else
+            hipLaunchKernelGGL((diag_kernel<false, 4>), dim3((unsigned)p.Bc), dim3(THREADS), exclusive ? DIAG_LDS_EXCLUSIVE : DIAG_LDS, main, p, j, nkb,
+                               want_g, wait_slot, wait_value, fin, publish);
         BARK_LAUNCH_CHECK();
         return mark_on(main);
     }
@@ -2302,7 +2690,11 @@ struct Sweep {
             while (S > 1 && S * n_tiles * p.Bc > SPLITK_SLOTS) --S;
         }
         if (S < 1) S = 1;
-        if (S > nkb) S = nkb;
+        // a slab on the critical path (the plain split of an under-filled step) may be shorter than a block row: its workgroup is
+        // bound by the latency of its k-tiles' DMA stages (~2.7 us each on an idle chip, 8 per block row), not by their MFMAs
+        int cap = nkb;
+        if (slots == SPLITK_SLOTS && (long)n_tiles * p.Bc * nkb * SPLIT_FINE <= SPLIT_FINE_MAX_WGS) cap = nkb * SPLIT_FINE;  // (see SPLIT_FINE)
+        if (S > cap) S = cap;
         if (S > SPLITK_MAX) S = SPLITK_MAX;
         return S;
     }
@@ -2636,7 +3028,15 @@ ChunkPlan plan_chunk(Sweep &sw, int64_t bc, int64_t C, bool timing, bool dev_wai
     // block rows: no difference measured (N = 512..896), plain.
     const bool pipeline_ok = !splitk && nrb >= PIPE_MIN_NRB;
     c.pipelined = pipeline_ok && ((bc % PLAIN_CHUNK_MULTIPLE) != 0 || nrb < PLAIN_MIN_NRB);
-    c.one_block = nrb == 1 && sw.fused && C == 0 && !timing;  // N <= 128: leaf walk + ONE launch per chunk (OneBlock)
+    // N <= 128: leaf walk + ONE launch per chunk (OneBlock); 128 < N <= 256: the same with the two-block kernel (two_block_kernel),
+    // while the codes of 256 points fit behind the factor image in LDS (up to 83 code words per point)
+    // ... and while it is the faster form (a workgroup runs its matrix's phases one after the other; the multi-launch sweep spreads a
+    // lone matrix over the chip and overlaps the phases of many): round 5, same box, sweep | two_block_kernel, ms —
+    //   N = 256:  x 1..8 0.103-0.105 | 0.107-0.109,  x 256 0.158 | 0.133,  x 512 0.247 | 0.257,  x 1024 0.486 | 0.502,  x 2048 0.88 | 0.96
+    //   N = 200:  x 32 0.105 | 0.097,  x 256 0.156 | 0.118,  x 512 0.245 | 0.227,  x 1024 0.473 | 0.447      N = 144 x 1024  0.468 | 0.400
+    const bool two_ok = nrb == 2 && DIAG_LDS + (size_t)sw.p.nW * 2 * NB * sizeof(uint32_t) + 2 * NB * sizeof(double) <= DIAG_LDS_EXCLUSIVE &&
+                        bc >= TWO_MIN_BC && (bc <= TWO_MAX_BC || sw.p.N <= TWO_ANY_BC_MAX_N);
+    c.one_block = (nrb == 1 || (BARK_TWO_BLOCK && two_ok)) && sw.fused && C == 0 && !timing;
     sw.p.Bc = (int)bc;  // lookahead() / split_factor() read the chunk size
     if (c.one_block) {
         c.pipelined = false;
@@ -2670,8 +3070,8 @@ ChunkPlan plan_chunk(Sweep &sw, int64_t bc, int64_t C, bool timing, bool dev_wai
     c.pre_update = splitk && bc <= DEVWAIT_MAX_BC;
     return c;
 }
-int plan_code(const ChunkPlan &c, bool splitk) {
-    if (c.one_block) return BARK_SCHED_ONE_BLOCK;
+int plan_code(const ChunkPlan &c, bool splitk, int nrb) {
+    if (c.one_block) return nrb == 2 ? BARK_SCHED_TWO_BLOCK : BARK_SCHED_ONE_BLOCK;
     if (c.paired) return BARK_SCHED_PAIRED;
     if (c.pipelined) return BARK_SCHED_PIPELINED;
     if (splitk) return c.lookahead_steps > 0 ? BARK_SCHED_SPLITK_LOOKAHEAD : BARK_SCHED_SPLITK;
@@ -2736,6 +3136,8 @@ int bark_mll_plan_query(int64_t N, int64_t C, int64_t m, int64_t B, int64_t Bc, 
     sw.splitk = L.splitk;
     sw.fused = !L.splitk && C == 0 && (size_t)2 * leaf_words * NB * sizeof(uint32_t) <= GEMM_LDS;
     sw.la_stream = sw.la_stream2 = reinterpret_cast<hipStream_t>(&sw);  // non-null: look-ahead possible (never dereferenced)
+    sw.p.nW = leaf_words;
+    sw.p.N = (int)N;
     const bool dw = device_wait_enabled().load();
     const int64_t last = B % Bc ? B % Bc : Bc;
     const ChunkPlan lastp = plan_chunk(sw, last, C, timing != 0, dw, true);
@@ -2743,8 +3145,8 @@ int bark_mll_plan_query(int64_t N, int64_t C, int64_t m, int64_t B, int64_t Bc, 
     out->n_chunks = (int32_t)((B + Bc - 1) / Bc);
     out->chunk = (int32_t)Bc;
     out->last_chunk = (int32_t)last;
-    out->schedule = plan_code(first, L.splitk);
-    out->last_schedule = plan_code(lastp, L.splitk);
+    out->schedule = plan_code(first, L.splitk, sw.nrb);
+    out->last_schedule = plan_code(lastp, L.splitk, sw.nrb);
     out->splitk_layout = L.splitk ? 1 : 0;
     out->fused_gram = sw.fused ? 1 : 0;
     out->dev_wait = first.dev_wait ? 1 : 0;
@@ -3198,3 +3600,14 @@ int bark_quadform_hip(const double *K_inv, const double *y, int64_t N, double *o
 }
 
 }  // extern "C"
+
+#ifdef BARK_DIAG_STAMPS
+extern "C" int bark_debug_diag_stamps(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bark::g_diag_stamps), sizeof(unsigned long long) * 64);
+}
+#endif
+#ifdef BARK_TWO_STAMPS
+extern "C" int bark_debug_two_stamps(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bark::g_two_stamps), sizeof(unsigned long long) * 16);
+}
+#endif

@@ -14,6 +14,9 @@ CASES = [
     (1, 1, 3, 0, None), (2, 5, 1, 0, None), (130, 300, 7, 0, None),
     # one block row (N <= 128): the single-launch evaluation (chol.hip OneBlock), incl. chunks and the full 128
     (64, 256, 50, 0, None), (100, 7, 13, 0, None), (128, 40, 50, 0, 16), (20, 3, 50, 0, None), (257, 64, 50, 0, None), (513, 48, 20, 0, 16),
+    # two block rows (128 < N <= 256): the single-launch evaluation by two_block_kernel, ragged second blocks, chunks, one matrix
+    # (chunks of 16 .. 384 matrices, more up to N = 224: plan_chunk; the others take the multi-launch sweep)
+    (129, 5, 50, 0, None), (144, 1, 50, 0, None), (200, 256, 50, 0, None), (255, 33, 13, 0, None), (256, 64, 50, 0, 24), (210, 600, 20, 0, None),
     (700, 100, 13, 0, None), (777, 33, 50, 0, None), (900, 12, 50, 0, None), (1100, 64, 50, 0, None),
     (1300, 40, 30, 0, 24), (1500, 9, 50, 0, None), (2100, 2, 50, 0, None), (2500, 20, 50, 0, None),
     (640, 16, 50, 90, None), (1000, 70, 25, 130, None), (1400, 3, 50, 300, None),
@@ -86,3 +89,38 @@ def test_inverse_export_through_the_pipelined_schedule():
     pick = [0, 255, 256, 299]
     want = orc.batched_mll(F2[pick], nz[pick], None, X, y, ft, include_scale=False, include_2pi=True)
     assert np.allclose(whole[pick], want, rtol=MLL_RTOL, atol=MLL_ATOL)
+
+
+def test_two_block_kernel_against_the_multi_launch_sweep():
+    """128 < N <= 256 (round 5): `two_block_kernel` evaluates a chunk in one launch after the leaf walk.  Against the sweep it
+    replaces — the instrumented call (`bark_mll_timing`) still takes the multi-launch plain schedule: leaf walk, Gram tile,
+    right-hand side, diag, rows, solve, diag — to 1e-12 relative (the right-hand-side update sums in another order), against the
+    oracle's LU route, and with the bushy forests whose leaf codes are bytes (13 code words per point instead of 5)."""
+    import torch
+
+    import bench
+    from bark_amd import _lib
+    from bark_amd.fitting import schedule_plan
+    from oracle import oracle as orc
+
+    assert schedule_plan(200, 64)["schedule"] == "two_block" and schedule_plan(200, 64, timing=True)["schedule"] == "plain"
+    assert schedule_plan(200, 64, leaf_words=84)["schedule"] == "plain"  # codes of 256 points no longer fit behind the factor image
+    assert schedule_plan(256, 8)["schedule"] == "plain" and schedule_plan(256, 512)["schedule"] == "plain"  # where the sweep is faster
+    assert schedule_plan(200, 512)["schedule"] == "two_block" and schedule_plan(256, 300, chunk=256)["last_schedule"] == "two_block"
+    for N, Bn, problem in ((129, 16, "unit"), (177, 40, "unit"), (256, 256, "unit"), (200, 17, "stress"), (240, 32, "mixed")):
+        wl = bench.Workload(N, 8, 50, Bn, seed_base=N, rank_offset=0, problem=problem)
+        wl.run()
+        torch.cuda.synchronize()
+        got = wl.mll_d.clone()
+        assert int(wl.info_d.abs().max().item()) == 0
+        wl.run()
+        torch.cuda.synchronize()
+        assert bool((wl.mll_d == got).all())  # reproducible
+        t = _lib.MllTiming()
+        wl.run(timing=t)
+        torch.cuda.synchronize()
+        assert (t.n_diag_launches, t.n_panel_launches, t.n_solve_launches) == (2, 1, 1)  # the sweep it replaces
+        assert torch.allclose(wl.mll_d, got, rtol=1e-12, atol=0.0), (N, Bn, float((wl.mll_d / got - 1).abs().max()))
+        pick = sorted({0, Bn // 2, Bn - 1})
+        want = orc.batched_mll(wl.forests[pick], wl.noise[pick], None, wl.X, wl.y, wl.ft, include_scale=False, include_2pi=True)
+        assert np.allclose(got.cpu().numpy()[pick], want, rtol=MLL_RTOL, atol=MLL_ATOL), (N, Bn)

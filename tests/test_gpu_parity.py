@@ -688,7 +688,9 @@ def test_not_positive_definite_raises(B):
 
 
 @pytest.mark.parametrize("N,dup,m,eps", [(90, 40, 50, 1e-3), (300, 150, 50, 1e-3), (300, 150, 200, 1e-3), (700, 600, 200, 1e-3),
-                                         (700, 600, 400, 1e-4)])
+                                         (700, 600, 400, 1e-4),
+                                         # 128 < N <= 256: two_block_kernel — the pivot in its first and in its second block
+                                         (200, 60, 50, 1e-3), (250, 200, 200, 1e-3), (256, 250, 400, 1e-4)])
 def test_not_positive_definite_reports_the_first_bad_pivot(B, N, dup, m, eps):
     """The index in the error is LAPACK potrf's `info`: the 1-based position of the first pivot that is not positive when the
     matrix is eliminated in order — also when it lies in a later 4-pivot block of factor16, a later 16 x 16 sub-block of
@@ -714,6 +716,13 @@ def test_not_positive_definite_reports_the_first_bad_pivot(B, N, dup, m, eps):
     with pytest.raises(np.linalg.LinAlgError, match="not positive definite") as exc:
         B.fit.batched_mll(F, [noise], None, X, y, ft, include_scale=False, include_2pi=True)
     assert int(re.search(r"pivot (\d+)", str(exc.value)).group(1)) == want, (str(exc.value), want)
+    if 128 < N <= 256:  # ... and through two_block_kernel, which takes chunks of 16 matrices and more: 16 copies of the forest
+        from bark_amd.fitting import schedule_plan
+
+        assert schedule_plan(N, 16, m=m)["schedule"] == "two_block"
+        with pytest.raises(np.linalg.LinAlgError, match="not positive definite") as exc:
+            B.fit.batched_mll(np.repeat(F, 16, axis=0), np.full(16, noise), None, X, y, ft, include_scale=False, include_2pi=True)
+        assert int(re.search(r"pivot (\d+)", str(exc.value)).group(1)) == want, (str(exc.value), want)
 
 
 def test_argument_validation_across_the_api(B):

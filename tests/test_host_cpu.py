@@ -348,7 +348,8 @@ SCHEDULE_TABLE = {
     "N=2048 x 256 (16 block rows)": ((2048, 256, 0, None), ("paired", 1, 0, 0, 0)),
     "N=1920 x 256 (15 block rows)": ((1920, 256, 0, None), ("pipelined", 1, 0, 0, 0)),
     "N=512 x 256": ((512, 256, 0, None), ("plain", 1, 0, 0, 0)),
-    "N=256 x 256": ((256, 256, 0, None), ("plain", 1, 0, 0, 0)),
+    "N=256 x 256 (two block rows: one launch)": ((256, 256, 0, None), ("two_block", 1, 0, 0, 0)),
+    "N=384 x 256": ((384, 256, 0, None), ("plain", 1, 0, 0, 0)),
     "N=64 x 256": ((64, 256, 0, None), ("one_block", 1, 0, 0, 0)),
     "lone N=6900 (look-ahead)": ((6900, 1, 0, None), ("splitk_lookahead", 0, 1, 1, 1)),
 }
@@ -370,6 +371,9 @@ def test_schedule_table_of_the_baseline_configs():
         d = schedule_plan(4096, 300, chunk=256)  # a ragged last chunk takes its own schedule
         assert (d["n_chunks"], d["last_chunk"], d["schedule"], d["last_schedule"]) == (2, 44, "paired", "pipelined")
         assert schedule_plan(64, 1, timing=True)["schedule"] == "plain"  # the instrumented call has no one-launch form
+        # two block rows in one launch (round 5): chunks of 16 .. 384 matrices, larger ones up to N = 224; otherwise the sweep
+        assert [schedule_plan(256, b)["schedule"] for b in (1, 15, 16, 384, 385)] == ["plain", "plain", "two_block", "two_block", "plain"]
+        assert schedule_plan(224, 2048)["schedule"] == "two_block" and schedule_plan(225, 2048)["schedule"] == "plain"
         _lib.lib().bark_device_wait(0)
         assert schedule_plan(1024, 1)["dev_wait"] == 0 and schedule_plan(4096, 8)["dev_gate"] == 0
     finally:
