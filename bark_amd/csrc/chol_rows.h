@@ -307,7 +307,14 @@ __global__ __launch_bounds__(THREADS, 2) void panel_split_kernel(Mats p, int j, 
         }
 }
 
-constexpr int RED_ROWS = 8;  // rows of a 128 x 128 tile per panel_reduce_kernel workgroup (4 doubles per thread)
+// (Round 5: 16 / 32 rows per workgroup — half / a quarter of the workgroups, two / four independent groups per thread — measured
+// slower, 0.3-1.7 % / 1-10 %: N = 4096 x 16 6.92 | 6.98 | 7.01 ms, N = 16384 x 1 25.16 | 25.57 | 26.20, N = 4096 x 1 1.66 | 1.70 | 1.85.  Beside
+// resident row workgroups the reduce launch lives in the third wave slot of a SIMD; many short workgroups fill it best.)
+#ifndef BARK_RED_ROWS
+#define BARK_RED_ROWS 8
+#endif
+constexpr int RED_ROWS = BARK_RED_ROWS;  // rows of a 128 x 128 tile per panel_reduce_kernel workgroup: 4 doubles per thread and group of 8 rows
+static_assert(RED_ROWS % 8 == 0 && NB % RED_ROWS == 0, "whole groups of 8 rows");
 // T = A - sum of the tile's S slabs (fixed order: bit-reproducible) for the n_tiles tiles from t_off on.
 // GEN == 0: A is read from (and T written to) the materialised matrix; GEN == 1 + LeafRep: A is generated from the
 // leaf codes exactly as form_tile does (MLL-only sweeps never materialise the Gram matrix).
@@ -317,53 +324,56 @@ __global__ __launch_bounds__(THREADS) void panel_reduce_kernel(Mats p, int j, in
     const int tl = blockIdx.x / (NB / RED_ROWS), part = blockIdx.x % (NB / RED_ROWS), b = blockIdx.y;
     const int t = t_off + tl;
     const int rb = t < n_right ? j : j + 1, cb = t < n_right ? j + 1 + t : j + 1;
-    const int e = part * RED_ROWS * NB + 4 * threadIdx.x;  // four consecutive entries of one tile row
-    const double *slab = slabs + (size_t)((size_t)b * n_tiles + tl) * S * NB * NB + e;
-    f64x2 s0 = {0.0, 0.0}, s1 = {0.0, 0.0};
-#pragma unroll 4
-    for (int s = 0; s < S; ++s) {
-        const f64x2 *src = reinterpret_cast<const f64x2 *>(slab + (size_t)s * NB * NB);
-        s0 += src[0];
-        s1 += src[1];
-    }
-    const int r = e >> 7, c0 = e & (NB - 1);
-    f64x2 *dst = reinterpret_cast<f64x2 *>(p.A + (size_t)b * p.bstride + ((size_t)rb * NB + r) * p.ld + (size_t)cb * NB + c0);
-    if (GEN == 0) {
-        dst[0] -= s0;
-        dst[1] -= s1;
-        return;
-    }
-    const int npad = p.nrb * NB, gi = rb * NB + r, gj0 = cb * NB + c0;
-    const uint32_t *lb = p.leafx + (size_t)b * p.nW * npad;
-    uint32_t cnt[4] = {0, 0, 0, 0};
-    for (int w = 0; w < p.nW; ++w) {
-        const uint32_t rw = lb[(size_t)w * npad + gi];
-        const uint4 cw = *reinterpret_cast<const uint4 *>(lb + (size_t)w * npad + gj0);
-        cnt[0] += code_count<(GEN > 0 ? GEN - 1 : 0)>(rw, cw.x);
-        cnt[1] += code_count<(GEN > 0 ? GEN - 1 : 0)>(rw, cw.y);
-        cnt[2] += code_count<(GEN > 0 ? GEN - 1 : 0)>(rw, cw.z);
-        cnt[3] += code_count<(GEN > 0 ? GEN - 1 : 0)>(rw, cw.w);
-    }
     const double inv_m = 1.0 / (double)p.m;
-    const bool has_scale = p.scale != nullptr, has_shift = p.shift != nullptr;
-    const double sc = has_scale ? p.scale[b] : 1.0, sh = has_shift ? p.shift[b] : 0.0, jitter = 1e-6 + p.noise[b];
-    double val[4];
+    const bool has_scale = GEN != 0 && p.scale != nullptr, has_shift = GEN != 0 && p.shift != nullptr;
+    const double sc = has_scale ? p.scale[b] : 1.0, sh = has_shift ? p.shift[b] : 0.0, jitter = GEN != 0 ? 1e-6 + p.noise[b] : 0.0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int gj = gj0 + i;
-        double v;
-        if (gi < p.N && gj < p.N) {
-            v = inv_m * (double)agree_count<(GEN > 0 ? GEN - 1 : 0)>(cnt[i], p.m);
-            if (has_shift) v = v - sh;
-            if (has_scale) v = sc * v;
-            if (gi == gj) v = v + jitter;
-        } else {
-            v = gi == gj ? 1.0 : 0.0;  // identity padding
+    for (int q = 0; q < RED_ROWS / 8; ++q) {  // (independent groups: their loads overlap)
+        const int e = (part * RED_ROWS + q * 8) * NB + 4 * threadIdx.x;  // four consecutive entries of one tile row
+        const double *slab = slabs + (size_t)((size_t)b * n_tiles + tl) * S * NB * NB + e;
+        f64x2 s0 = {0.0, 0.0}, s1 = {0.0, 0.0};
+#pragma unroll 4
+        for (int s = 0; s < S; ++s) {
+            const f64x2 *src = reinterpret_cast<const f64x2 *>(slab + (size_t)s * NB * NB);
+            s0 += src[0];
+            s1 += src[1];
         }
-        val[i] = v;
+        const int r = e >> 7, c0 = e & (NB - 1);
+        f64x2 *dst = reinterpret_cast<f64x2 *>(p.A + (size_t)b * p.bstride + ((size_t)rb * NB + r) * p.ld + (size_t)cb * NB + c0);
+        if (GEN == 0) {
+            dst[0] -= s0;
+            dst[1] -= s1;
+            continue;
+        }
+        const int npad = p.nrb * NB, gi = rb * NB + r, gj0 = cb * NB + c0;
+        const uint32_t *lb = p.leafx + (size_t)b * p.nW * npad;
+        uint32_t cnt[4] = {0, 0, 0, 0};
+        for (int w = 0; w < p.nW; ++w) {
+            const uint32_t rw = lb[(size_t)w * npad + gi];
+            const uint4 cw = *reinterpret_cast<const uint4 *>(lb + (size_t)w * npad + gj0);
+            cnt[0] += code_count<(GEN > 0 ? GEN - 1 : 0)>(rw, cw.x);
+            cnt[1] += code_count<(GEN > 0 ? GEN - 1 : 0)>(rw, cw.y);
+            cnt[2] += code_count<(GEN > 0 ? GEN - 1 : 0)>(rw, cw.z);
+            cnt[3] += code_count<(GEN > 0 ? GEN - 1 : 0)>(rw, cw.w);
+        }
+        double val[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gj = gj0 + i;
+            double v;
+            if (gi < p.N && gj < p.N) {
+                v = inv_m * (double)agree_count<(GEN > 0 ? GEN - 1 : 0)>(cnt[i], p.m);
+                if (has_shift) v = v - sh;
+                if (has_scale) v = sc * v;
+                if (gi == gj) v = v + jitter;
+            } else {
+                v = gi == gj ? 1.0 : 0.0;  // identity padding
+            }
+            val[i] = v;
+        }
+        dst[0] = (f64x2){val[0], val[1]} - s0;
+        dst[1] = (f64x2){val[2], val[3]} - s1;
     }
-    dst[0] = (f64x2){val[0], val[1]} - s0;
-    dst[1] = (f64x2){val[2], val[3]} - s1;
 }
 
 }  // namespace
