@@ -49,7 +49,7 @@ class MllPlan(ctypes.Structure):
         "pre_update", "lookahead_steps", "splitk_steps", "nrb", "ncb")]
 
 
-SCHEDULES = ("one_block", "plain", "paired", "pipelined", "splitk", "splitk_lookahead", "two_block")  # BARK_SCHED_*
+SCHEDULES = ("one_block", "plain", "paired", "pipelined", "splitk", "splitk_lookahead", "two_block", "multi_block")  # BARK_SCHED_*
 
 
 # every exported symbol of include/*.h: name -> (restype, argtypes)

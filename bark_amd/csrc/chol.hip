@@ -176,6 +176,24 @@ constexpr int DIAG8_MAX_BC = 256;  // one-launch kernels (N <= 256): eight waves
 #endif
 // ... for chunks of TWO_MIN_BC .. TWO_MAX_BC matrices, and larger chunks up to TWO_ANY_BC_MAX_N points (plan_chunk has the table)
 constexpr int TWO_MIN_BC = 16, TWO_MAX_BC = 384, TWO_ANY_BC_MAX_N = 224;
+#ifndef BARK_MULTI_BLOCK
+#define BARK_MULTI_BLOCK 1  // 256 < N <= 512, MLL only: the one-launch evaluation by multi_block_kernel
+#endif
+// Chunks of MB_MIN_BC .. MB_MAX_BC matrices: the kernel runs a matrix's block steps one after the other on ONE CU (~0.38 ms at N = 512
+// whatever the batch), the sweep spreads a matrix over the chip — round 5, same box, sweep | multi_block_kernel, ms:
+//   N = 512:  x 16 0.20 | 0.38,  x 64 0.30 | 0.42,  x 96 0.35 | 0.41,  x 128 0.38 | 0.42,  x 192 0.47 | 0.44,  x 256 0.52 | 0.46,  x 384 0.82 | 0.86
+//   N = 384:  x 128 0.216 | 0.227,  x 256 0.298 | 0.252        N = 300:  x 64 0.190 | 0.198,  x 128 0.214 | 0.209,  x 256 0.292 | 0.230
+#ifndef BARK_MB_MIN_BC
+#define BARK_MB_MIN_BC 160
+#endif
+#ifndef BARK_MB_MAX_BC
+#define BARK_MB_MAX_BC 320
+#endif
+constexpr int MB_MIN_BC = BARK_MB_MIN_BC, MB_MAX_BC = BARK_MB_MAX_BC;
+// dynamic LDS of multi_block_kernel: factor image, vec, red, y and z (four blocks each), three A-panel stages, the leaf codes
+inline size_t mb_lds_bytes(int nW, int nrb) {
+    return (size_t)(NBLK * SB * SB + 2 * NB + 8 + 2 * MB_MAX_NRB * NB + 3 * MB_STAGE) * sizeof(double) + (size_t)nW * nrb * NB * sizeof(uint32_t);
+}
 #ifndef BARK_PIPE_MIN_NRB
 #define BARK_PIPE_MIN_NRB 8
 #endif
@@ -303,6 +321,7 @@ int set_lds_limits() {
         };
         hipError_t e = set(reinterpret_cast<const void *>(diag_kernel<false, 4>), DIAG_LDS_EXCLUSIVE);
         if (e == hipSuccess) e = set(reinterpret_cast<const void *>(diag_kernel<true, 4>), DIAG_LDS_EXCLUSIVE);
+        if (e == hipSuccess) e = set(reinterpret_cast<const void *>(multi_block_kernel), DIAG_LDS_EXCLUSIVE);
         if (e == hipSuccess) e = set(reinterpret_cast<const void *>(two_block_kernel<4>), DIAG_LDS_EXCLUSIVE);
         if (e == hipSuccess) e = set(reinterpret_cast<const void *>(two_block_kernel<8>), DIAG_LDS_EXCLUSIVE);
         if (e == hipSuccess) e = set(reinterpret_cast<const void *>(diag_kernel<false, 8>), DIAG_LDS_EXCLUSIVE);
@@ -535,7 +554,9 @@ struct Sweep {
         const size_t lds_bytes = DIAG_LDS + (size_t)p.nW * NB * sizeof(uint32_t);
         // eight waves (factor_tile8) while every matrix of the chunk has a CU to itself; beyond that two four-wave workgroups share one
         const bool w8 = BARK_DIAG_WAVES8 && p.Bc <= DIAG8_MAX_BC;
-        if (nrb == 2) {  // two_block_kernel: codes of 256 points + z_0 + U_01' z_0 behind the factor image
+        if (nrb >= 3) {  // multi_block_kernel (256 < N <= 512)
+            hipLaunchKernelGGL(multi_block_kernel, dim3((unsigned)p.Bc), dim3(512), mb_lds_bytes(p.nW, nrb), main, p, ob);
+        } else if (nrb == 2) {  // two_block_kernel: codes of 256 points + z_0 + U_01' z_0 behind the factor image
             const size_t lds2 = DIAG_LDS + (size_t)p.nW * 2 * NB * sizeof(uint32_t) + 2 * NB * sizeof(double);
             if (w8)
                 hipLaunchKernelGGL(two_block_kernel<8>, dim3((unsigned)p.Bc), dim3(512), lds2, main, p, ob);
@@ -954,6 +975,11 @@ ChunkPlan plan_chunk(Sweep &sw, int64_t bc, int64_t C, bool timing, bool dev_wai
     const bool two_ok = nrb == 2 && DIAG_LDS + (size_t)sw.p.nW * 2 * NB * sizeof(uint32_t) + 2 * NB * sizeof(double) <= DIAG_LDS_EXCLUSIVE &&
                         bc >= TWO_MIN_BC && (bc <= TWO_MAX_BC || sw.p.N <= TWO_ANY_BC_MAX_N);
     c.one_block = (nrb == 1 || (BARK_TWO_BLOCK && two_ok)) && sw.fused && C == 0 && !timing;
+    // 256 < N <= 512: multi_block_kernel (three or four block rows in one launch, eight waves), whatever layout the sweep would
+    // take for the chunk, while the codes of the matrix's points fit beside the factor image and the GEMM stages in LDS
+    if (BARK_MULTI_BLOCK && (nrb == 3 || nrb == 4) && C == 0 && !timing && bc >= MB_MIN_BC && bc <= MB_MAX_BC &&
+        mb_lds_bytes(sw.p.nW, nrb) <= DIAG_LDS_EXCLUSIVE)
+        c.one_block = true;
     sw.p.Bc = (int)bc;  // lookahead() / split_factor() read the chunk size
     if (c.one_block) {
         c.pipelined = false;
@@ -988,7 +1014,7 @@ ChunkPlan plan_chunk(Sweep &sw, int64_t bc, int64_t C, bool timing, bool dev_wai
     return c;
 }
 int plan_code(const ChunkPlan &c, bool splitk, int nrb) {
-    if (c.one_block) return nrb == 2 ? BARK_SCHED_TWO_BLOCK : BARK_SCHED_ONE_BLOCK;
+    if (c.one_block) return nrb >= 3 ? BARK_SCHED_MULTI_BLOCK : nrb == 2 ? BARK_SCHED_TWO_BLOCK : BARK_SCHED_ONE_BLOCK;
     if (c.paired) return BARK_SCHED_PAIRED;
     if (c.pipelined) return BARK_SCHED_PIPELINED;
     if (splitk) return c.lookahead_steps > 0 ? BARK_SCHED_SPLITK_LOOKAHEAD : BARK_SCHED_SPLITK;
@@ -1524,6 +1550,9 @@ extern "C" int bark_debug_diag_stamps(unsigned long long *out) {
 }
 #endif
 #ifdef BARK_TWO_STAMPS
+extern "C" int bark_debug_mb_stamps(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bark::g_mb_stamps), sizeof(unsigned long long) * 64);
+}
 extern "C" int bark_debug_two_stamps(unsigned long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bark::g_two_stamps), sizeof(unsigned long long) * 16);
 }

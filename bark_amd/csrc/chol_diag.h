@@ -1110,6 +1110,282 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void two_block_kernel(Mat
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// multi_block_kernel (round 5): matrices of THREE or FOUR block rows (256 < N <= 512) in one launch, eight waves, one workgroup
+// per matrix — two_block_kernel's scheme with the off-diagonal GEMMs in the same workgroup.  The multi-launch sweep of 256
+// such matrices moves every tile through HBM three times (T written by the row launch, read and rewritten as U by the solve,
+// read as a panel by the next row launch: 0.5 GB per pass against 36 MB of L2) and takes 0.52 ms at N = 512; a CU's own MFMA
+// share of one matrix is 146 us.  Per block step j:
+//   D_j = A_jj (generated) - sum_{a<j} U[a,j]'U[a,j]     mb_update: diag_update's product loop over ALL block rows above
+//   factor_tile8 -> W_j ; z_j ; log|D_j|
+//   for every block column c > j (a wave owns 16 columns of the tile):
+//       T = A_jc (generated) - sum_{r < 128 j} U[r, j-block]' U[r, c-cols]    A fragments from an LDS-DMA stage of the panel
+//                                                                            (a ring of three 16-row stages beside the factor image),
+//                                                                            B fragments straight from L2 (16 columns a wave)
+//       U[j,c] = W_j' T     T in its accumulators IS the B operand of this product (D layout == B layout per 16 x 16 block)
+//       y_c -= U[j,c]' z_j  (y and z live in LDS)
+// U tiles go to the workspace (L2-resident scratch); nothing else leaves the CU until the MLL.  Per element the k order of every
+// sum is ascending as in the sweep; the right-hand-side update sums in two_block_kernel's order.
+// ---------------------------------------------------------------------------------------------
+constexpr int MB_MAX_NRB = 4;
+constexpr int MB_STAGE = BK * LDS_LD;  // one operand: 16 rows x (128 + 16) doubles
+
+// D = pre - sum over the block rows a < nkb of panel_a' panel_a on this wave's nine sub-blocks (waves 0-3; diag_update's loop
+// with every block row above instead of the first and the last); the product stages alias S.
+// Eight waves: wave W < 4 takes the entries [0, 5) of UpperBlocks<W>, wave W + 4 the entries [5, 9) — the product is bound by the
+// MFMA pipes of the CU (36 sub-blocks x 32 MFMAs per block row), and four waves left every pipe half idle.
+template <int W, int LO, int HI>
+__device__ __forceinline__ void mb_update(const double *__restrict__ col0, long ld, int nkb, double *lds, double *S, int wave_u, int lane,
+                                          int lr, int lk, const Mats &p, int b, int rep, const uint32_t *codes, int cs, int goff) {
+    using T = UpperBlocks<W>;
+    double pre[9][4];
+    const GenCtx g = gen_ctx(p, b, rep);
+#pragma unroll
+    for (int i = LO; i < HI; ++i) {
+        const int r0 = goff + T::rb[i] * 16 + lk;
+        const int gi[4] = {r0, r0 + 4, r0 + 8, r0 + 12};
+        gen_rows4(g, codes, cs, gi, goff + T::cb[i] * 16 + lr, pre[i]);
+    }
+    f64x4 acc[9];
+#pragma unroll
+    for (int i = LO; i < HI; ++i) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    const int nk = nkb * (NB / BK);  // k-tiles of the whole panel U[0 : 128 nkb, j-block]
+    auto stage = [&](int kt, double *st) {  // wave w moves rows w and w + 8 of the k-tile
+        dma_row(col0 + (size_t)(kt * BK + wave_u) * ld + lane * 2, st + wave_u * LDS_LD);
+        dma_row(col0 + (size_t)(kt * BK + wave_u + 8) * ld + lane * 2, st + (wave_u + 8) * LDS_LD);
+    };
+    if (nk > 0) {
+        stage(0, lds);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) stage(kt + 1, lds + ((kt + 1) & 1) * UPD_STAGE);
+            const double *st = lds + (kt & 1) * UPD_STAGE;
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                double fr[8];
+#pragma unroll
+                for (int blk = 0; blk < 8; ++blk)
+                    if (blk >= W) fr[blk] = st[(kk * 4 + lk) * LDS_LD + blk * 16 + lr];
+#pragma unroll
+                for (int i = LO; i < HI; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[T::rb[i]], fr[T::cb[i]], acc[i], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = LO; i < HI; ++i) {
+        double *blk = S + blk_off(T::rb[i], T::cb[i]);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) blk[(lk + 4 * v) * SB + lr] = pre[i][v] - acc[i][v];
+    }
+}
+
+// Tile (j, c), this wave's 16 columns ct: T, then U[j,c] = W_j' T, stored; y_c -= U' z_j in LDS.  All eight waves (barriers inside).
+// NOT inlined: inside multi_block_kernel's body its 64 + 64 accumulator registers beside the factorisation's spilled ~290 VGPRs;
+// as a function of its own the kernel allocates 248 and spills none.  The LDS arrays arrive as offsets into the kernel's dynamic LDS
+// (pointers through a call would be generic: flat loads instead of ds_read).
+__device__ __attribute__((noinline)) void mb_offdiag(const Mats &p, int b, int rep, int cs, int stage_off, int codes_off, double *Ab, int j,
+                                                     int c, int zj_off, int yc_off, int wave_u, int lane, int lr, int lk) {
+    extern __shared__ __attribute__((aligned(16))) double mb_lds[];
+    const double *S = mb_lds;
+    double *stage = mb_lds + stage_off;
+    const uint32_t *codes = reinterpret_cast<const uint32_t *>(mb_lds + codes_off);
+    const double *zj = mb_lds + zj_off;
+    double *yc = mb_lds + yc_off;
+    const GenCtx g = gen_ctx(p, b, rep);
+    const int ct = wave_u;
+    f64x4 tacc[NSB];
+#pragma unroll
+    for (int kt = 0; kt < NSB; ++kt) tacc[kt] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    const int nk = j * (NB / BK);
+    if (nk > 0) {  // (workgroup-uniform)
+        const double *Apan = Ab + (size_t)j * NB;                                        // U[0 : 128 j, j-block]: rows k, 128 columns
+        const double *Bcol = Ab + (size_t)c * NB + ct * SB + lr + (size_t)lk * p.ld;     // this lane's B element of row 4 s + lk
+        auto stage_a = [&](int kt, double *st) {  // wave w moves rows w and w + 8 of the k-tile
+            dma_row(Apan + (size_t)(kt * BK + wave_u) * p.ld + lane * 2, st + wave_u * LDS_LD);
+            dma_row(Apan + (size_t)(kt * BK + wave_u + 8) * p.ld + lane * 2, st + (wave_u + 8) * LDS_LD);
+        };
+        // ring of three stages, two in flight: the 32 MFMAs of a k-tile are ~2 K cycles a wave, a DMA round trip is more.  The B
+        // elements ride in three register sets by the stage's slot (the loop is unrolled by three: no copies of values in flight)
+        double bb[3][4];
+        auto issue = [&](int kt, int slot) {  // two DMA rows + four B elements: six VM operations a wave
+            stage_a(kt, stage + slot * MB_STAGE);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) bb[slot][kk] = Bcol[(size_t)(kt * BK + kk * 4) * p.ld];
+        };
+        auto step = [&](int kt, int slot) {  // slot == kt % 3, a compile-time constant at every call
+            if (kt + 1 < nk)
+                asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kt + 2 < nk) issue(kt + 2, (slot + 2) % 3);  // that slot was read in iteration kt - 1: every wave is past the barrier
+            const double *st = stage + slot * MB_STAGE;
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+#pragma unroll
+                for (int t8 = 0; t8 < NSB; ++t8)
+                    tacc[t8] = __builtin_amdgcn_mfma_f64_16x16x4f64(st[(kk * 4 + lk) * LDS_LD + t8 * SB + lr], bb[slot][kk], tacc[t8], 0, 0, 0);
+            }
+        };
+        issue(0, 0);
+        if (nk > 1) issue(1, 1);
+        for (int kt = 0; kt < nk; kt += 3) {
+            step(kt, 0);
+            if (kt + 1 < nk) step(kt + 1, 1);
+            if (kt + 2 < nk) step(kt + 2, 2);
+        }
+        __syncthreads();
+    }
+    // T = A_jc - (the sum) in place: tacc[kt] becomes the B fragments of k-tile kt (T[16 kt + 4 kk + lk][16 ct + lr], kk = 0..3)
+#pragma unroll
+    for (int kt = 0; kt < NSB; ++kt) {
+        double av[4];
+        const int r0 = j * NB + kt * SB + lk;
+        const int gi[4] = {r0, r0 + 4, r0 + 8, r0 + 12};
+        gen_rows4(g, codes, cs, gi, c * NB + ct * SB + lr, av);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) tacc[kt][kk] = av[kk] - tacc[kt][kk];
+        __builtin_amdgcn_sched_barrier(0);  // one k-tile's generation at a time
+    }
+    f64x4 acc[NSB];
+#pragma unroll
+    for (int rt = 0; rt < NSB; ++rt) acc[rt] = (f64x4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kt = 0; kt < NSB; ++kt) {  // k ascending for every element; W_j is upper triangular: row tiles rt >= kt only
+#pragma unroll
+        for (int rt = 0; rt < NSB; ++rt) {
+            if (rt >= kt) {
+                const double *wb = S + blk_off(kt, rt);
+#pragma unroll
+                for (int kk = 0; kk < SB / 4; ++kk)
+                    acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(wb[(kk * 4 + lk) * SB + lr], tacc[kt][kk], acc[rt], 0, 0, 0);
+            }
+        }
+    }
+    double *U = Ab + (size_t)j * NB * p.ld + (size_t)c * NB;
+    double sum = 0.0;
+#pragma unroll
+    for (int rt = 0; rt < NSB; ++rt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = rt * SB + lk + 4 * v;
+            U[(size_t)r * p.ld + ct * SB + lr] = acc[rt][v];
+            sum = fma(acc[rt][v], zj[r], sum);
+        }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    if (lk == 0) yc[ct * SB + lr] -= sum;
+}
+
+#ifdef BARK_TWO_STAMPS
+__device__ unsigned long long g_mb_stamps[64];
+#endif
+__global__ __launch_bounds__(512, 1) void multi_block_kernel(Mats p, OneBlock ob) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const Lane q = lane_of(tid);
+    const int wave = tid >> 6, lane = tid & 63, lr = q.lr, lk = q.lk;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int nrb = p.nrb, cs = nrb * NB;  // points per code plane == npad
+    double *Ab = p.A + (size_t)b * p.bstride;
+    double *S = lds;                        // packed upper block triangle, NBLK x [16][16]
+    double *vec = lds + NBLK * SB * SB;     // [2][128] y | upper-half partial sums
+    double *red = vec + 2 * NB;             // [8]
+    double *ylds = red + 8;                 // [nrb][128] the right-hand side, updated in place
+    double *zlds = ylds + MB_MAX_NRB * NB;  // [nrb][128] z_j
+    double *stage = zlds + MB_MAX_NRB * NB; // [3][16][LDS_LD] A panel stages of the off-diagonal GEMMs (a ring)
+    uint32_t *codes = reinterpret_cast<uint32_t *>(stage + 3 * MB_STAGE);  // [nW][cs]
+    {
+        const uint32_t *lb = p.leafx + (size_t)b * p.nW * cs;
+        for (int e = tid; e < p.nW * cs; e += 512) codes[e] = lb[e];
+        for (int e = tid; e < cs; e += 512) ylds[e] = e < p.N ? ob.y[e] : 0.0;
+    }
+    __syncthreads();
+    double quad_sum = 0.0, logsum_sum = 0.0;  // over the blocks (thread 0: wave 0 ran factor16)
+    int bad_all = 0;
+#ifdef BARK_TWO_STAMPS
+    int stamp_n = 0;
+#define MB_STAMP() do { if (tid == 0 && b == 0) g_mb_stamps[stamp_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MB_STAMP() do {} while (0)
+#endif
+    MB_STAMP();
+    // (a block step per compile-time index: as a run-time loop the body — mb_update, factor_tile8, mb_offdiag — spilled 150 VGPRs)
+    auto block = [&](auto JJ) {
+        constexpr int j = decltype(JJ)::value;
+        if (j >= nrb) return;  // workgroup-uniform
+        double logsum = 0.0, pacc = 1.0;
+        int bad = 0;
+        const double *col0 = Ab + (size_t)j * NB;  // U[0 : 128 j, j-block]
+        switch (wave_u) {  // (wave-uniform; every wave runs the same barriers)
+            case 0: mb_update<0, 0, 5>(col0, p.ld, j, lds, S, wave_u, lane, lr, lk, p, b, ob.rep, codes, cs, j * NB); break;
+            case 1: mb_update<1, 0, 5>(col0, p.ld, j, lds, S, wave_u, lane, lr, lk, p, b, ob.rep, codes, cs, j * NB); break;
+            case 2: mb_update<2, 0, 5>(col0, p.ld, j, lds, S, wave_u, lane, lr, lk, p, b, ob.rep, codes, cs, j * NB); break;
+            case 3: mb_update<3, 0, 5>(col0, p.ld, j, lds, S, wave_u, lane, lr, lk, p, b, ob.rep, codes, cs, j * NB); break;
+            case 4: mb_update<0, 5, 9>(col0, p.ld, j, lds, S, wave_u, lane, lr, lk, p, b, ob.rep, codes, cs, j * NB); break;
+            case 5: mb_update<1, 5, 9>(col0, p.ld, j, lds, S, wave_u, lane, lr, lk, p, b, ob.rep, codes, cs, j * NB); break;
+            case 6: mb_update<2, 5, 9>(col0, p.ld, j, lds, S, wave_u, lane, lr, lk, p, b, ob.rep, codes, cs, j * NB); break;
+            default: mb_update<3, 5, 9>(col0, p.ld, j, lds, S, wave_u, lane, lr, lk, p, b, ob.rep, codes, cs, j * NB); break;
+        }
+        __syncthreads();
+        MB_STAMP();
+        const int left = p.N - j * NB;
+        const int nsb = left >= NB ? NSB : (left + SB - 1) / SB;  // live sub-blocks of this block; the rest is identity padding
+        factor_tile8<true>(S, nsb, false, wave_u, lane, lr, lk, logsum, pacc, bad);
+        MB_STAMP();
+        // z_j = W_j' y_j ; |z_j|^2 (diag_kernel's last phase on the first four waves)
+        {
+            const double *yj = ylds + j * NB;
+            const int c = tid & (NB - 1), half = tid >> 7, cbk = c >> 4, cc = c & 15;  // (half = 2, 3 do nothing)
+            double part = 0.0;
+#pragma unroll
+            for (int i = 0; i < NSB / 2; ++i) {
+                const int rbk = half * (NSB / 2) + i;
+                if (rbk <= cbk && half < 2) {
+                    const double *col = S + blk_off(rbk, cbk) + cc;
+#pragma unroll
+                    for (int rr = 0; rr < SB; ++rr) part = fma(col[rr * SB], yj[rbk * SB + rr], part);
+                }
+            }
+            if (half == 1) vec[NB + c] = part;
+            __syncthreads();
+            double zz = 0.0;
+            if (!half) {
+                const double z = part + vec[NB + c];
+                zlds[j * NB + c] = z;
+                zz = z * z;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) zz += __shfl_xor(zz, off);
+            if (lane == 0) red[wave] = zz;
+        }
+        __syncthreads();
+        quad_sum += red[0] + red[1];
+        logsum_sum += logsum;
+        bad_all = (bad && !bad_all) ? j * NB + bad : bad_all;
+        MB_STAMP();
+#pragma unroll 1
+        for (int c = j + 1; c < nrb; ++c) {
+            mb_offdiag(p, b, ob.rep, cs, (int)(stage - lds), (int)(reinterpret_cast<double *>(codes) - lds), Ab, j, c,
+                       (int)(zlds - lds) + j * NB, (int)(ylds - lds) + c * NB, wave_u, lane, lr, lk);
+            __syncthreads();  // U[j,c] (global: this workgroup's own stores) and y_c are visible to every wave
+        }
+        MB_STAMP();
+    };
+    block(std::integral_constant<int, 0>{});
+    block(std::integral_constant<int, 1>{});
+    block(std::integral_constant<int, 2>{});
+    block(std::integral_constant<int, 3>{});
+    if (tid == 0) {  // finish_mll_kernel's arithmetic (quick_inverse.py:38 / mcmc_record_mll.py:73)
+        double v = -quad_sum - 2.0 * logsum_sum;
+        if (ob.include_2pi) v = v - (double)p.N * log(2.0 * M_PI);
+        ob.mll[b] = 0.5 * v;
+        p.info[b] = *ob.fault ? -1 : bad_all;
+    }
+}
+
 // D = P - sum_k U[k,j]'U[k,j] over the nkb block rows above, on the 36 sub-blocks of the upper block triangle, in place in
 // the stored diagonal tile: diag_update's arithmetic (per element the same MFMA sequence: block rows in order, k ascending,
 // four k per MFMA — identical bits) by 9 workgroups x 4 waves per matrix, one sub-block per wave, operands straight from

@@ -17,6 +17,8 @@ CASES = [
     # two block rows (128 < N <= 256): the single-launch evaluation by two_block_kernel, ragged second blocks, chunks, one matrix
     # (chunks of 16 .. 384 matrices, more up to N = 224: plan_chunk; the others take the multi-launch sweep)
     (129, 5, 50, 0, None), (144, 1, 50, 0, None), (200, 256, 50, 0, None), (255, 33, 13, 0, None), (256, 64, 50, 0, 24), (210, 600, 20, 0, None),
+    # three / four block rows (256 < N <= 512) in chunks of 160 .. 320 matrices: multi_block_kernel; ragged last blocks, a chunked batch
+    (300, 200, 50, 0, None), (400, 170, 13, 0, None), (512, 256, 50, 0, None), (511, 400, 20, 0, 200), (385, 160, 50, 0, None),
     (700, 100, 13, 0, None), (777, 33, 50, 0, None), (900, 12, 50, 0, None), (1100, 64, 50, 0, None),
     (1300, 40, 30, 0, 24), (1500, 9, 50, 0, None), (2100, 2, 50, 0, None), (2500, 20, 50, 0, None),
     (640, 16, 50, 90, None), (1000, 70, 25, 130, None), (1400, 3, 50, 300, None),
@@ -124,3 +126,71 @@ def test_two_block_kernel_against_the_multi_launch_sweep():
         pick = sorted({0, Bn // 2, Bn - 1})
         want = orc.batched_mll(wl.forests[pick], wl.noise[pick], None, wl.X, wl.y, wl.ft, include_scale=False, include_2pi=True)
         assert np.allclose(got.cpu().numpy()[pick], want, rtol=MLL_RTOL, atol=MLL_ATOL), (N, Bn)
+
+
+def test_multi_block_kernel_against_the_multi_launch_sweep():
+    """256 < N <= 512 (round 5): `multi_block_kernel` evaluates a chunk of 160 .. 320 matrices in one launch after the leaf walk —
+    three or four block rows, the off-diagonal GEMMs in the same workgroup.  Against the sweep it replaces (the instrumented call takes
+    the multi-launch schedule) to 1e-12 relative, against the oracle's LU route, with byte codes (bushy forests), and the index of a
+    non-positive pivot in the second, third and fourth block."""
+    import re
+
+    import torch
+
+    import bark_amd.fitting as fit
+    import bench
+    from bark_amd import _lib, synthetic as syn
+    from bark_amd.fitting import schedule_plan
+    from oracle import oracle as orc
+
+    assert schedule_plan(512, 256)["schedule"] == "multi_block" and schedule_plan(300, 160)["schedule"] == "multi_block"
+    assert schedule_plan(512, 64)["schedule"] != "multi_block" and schedule_plan(512, 400)["schedule"] == "plain"
+    assert schedule_plan(512, 256, timing=True)["schedule"] == "plain" and schedule_plan(512, 256, leaf_words=40)["schedule"] == "plain"
+    for N, Bn, problem in ((257, 160, "unit"), (384, 200, "unit"), (512, 256, "unit"), (380, 161, "stress"), (500, 170, "mixed")):
+        wl = bench.Workload(N, 8, 50, Bn, seed_base=N, rank_offset=0, problem=problem)
+        words = int(_lib.lib().bark_leaf_words(wl.pf.info_ref))  # 5 for prior forests, 13 (bytes) for the bushy ones: three block rows only
+        assert schedule_plan(N, Bn, leaf_words=words)["schedule"] == "multi_block", (N, Bn, words)
+        wl.run()
+        torch.cuda.synchronize()
+        got = wl.mll_d.clone()
+        assert int(wl.info_d.abs().max().item()) == 0
+        wl.run()
+        torch.cuda.synchronize()
+        assert bool((wl.mll_d == got).all())  # reproducible
+        t = _lib.MllTiming()
+        wl.run(timing=t)
+        torch.cuda.synchronize()
+        assert t.n_diag_launches == (N + 127) // 128  # the sweep it replaces
+        assert torch.allclose(wl.mll_d, got, rtol=1e-12, atol=0.0), (N, Bn, float((wl.mll_d / got - 1).abs().max()))
+        pick = sorted({0, Bn // 2, Bn - 1})
+        want = orc.batched_mll(wl.forests[pick], wl.noise[pick], None, wl.X, wl.y, wl.ft, include_scale=False, include_2pi=True)
+        assert np.allclose(got.cpu().numpy()[pick], want, rtol=MLL_RTOL, atol=MLL_ATOL), (N, Bn)
+    # K - eps I: the elimination fails where the forest's rank runs out, or at a duplicated point (tests/test_gpu_parity.py::
+    # test_not_positive_definite_reports_the_first_bad_pivot has the construction): pivot 150 (second block) and 264 (third block);
+    # 160 copies of the forest -> multi_block_kernel.  (A fourth-block failure needs a forest of rank > 384, i.e. more leaf-code
+    # words than fit beside four blocks' LDS: such forests take the sweep, where the parity suite covers the index.)
+    from bark_amd.forest import PackedForest
+
+    X1, y1, bounds1, ft1 = syn.mixed_problem(300, seed=300)
+    X1 = X1.copy()
+    X1[149] = X1[0]
+    F1 = syn.sample_prior_forests(1, 170, bounds1, ft1, seed=300)  # 170 trees: ~14 code words, the most that fit beside three blocks
+    X2, y2, _b2, ft2 = syn.unit_cube_problem(384, 8, seed=384)
+    F2 = syn.full_binary_forests(1, 100, 8, 2, np.random.default_rng(384))
+    for X, y, ft, F, eps, expect in ((X1, y1, ft1, F1, 1e-3, 150), (X2, y2, ft2, F2, 1e-4, 264)):
+        N = X.shape[0]
+        noise = -1e-6 - eps
+        A, want = orc.forest_gram_matrix(F[0], X, X, ft) + (1e-6 + noise) * np.eye(N), 0
+        for k in range(N):
+            if not A[k, k] > 0.0:
+                want = k + 1
+                assert A[k, k] < -1e-4, A[k, k]
+                break
+            A[k + 1:, k + 1:] -= np.outer(A[k + 1:, k], A[k, k + 1:]) / A[k, k]
+        assert want == expect
+        Frep = np.repeat(F, 160, axis=0)
+        words = int(_lib.lib().bark_leaf_words(PackedForest(Frep, ft).info_ref))
+        assert schedule_plan(N, 160, m=F.shape[1], leaf_words=words)["schedule"] == "multi_block", words
+        with pytest.raises(np.linalg.LinAlgError, match="not positive definite") as exc:
+            fit.batched_mll(Frep, np.full(160, noise), None, X, y, ft, include_scale=False, include_2pi=True)
+        assert int(re.search(r"pivot (\d+)", str(exc.value)).group(1)) == want, (str(exc.value), want)

@@ -347,9 +347,11 @@ SCHEDULE_TABLE = {
     "N=4096 x 16": ((4096, 16, 0, None), ("pipelined", 1, 1, 1, 0)),
     "N=2048 x 256 (16 block rows)": ((2048, 256, 0, None), ("paired", 1, 0, 0, 0)),
     "N=1920 x 256 (15 block rows)": ((1920, 256, 0, None), ("pipelined", 1, 0, 0, 0)),
-    "N=512 x 256": ((512, 256, 0, None), ("plain", 1, 0, 0, 0)),
+    "N=512 x 256 (four block rows: one launch)": ((512, 256, 0, None), ("multi_block", 1, 0, 0, 0)),
+    "N=512 x 64": ((512, 64, 0, None), ("splitk", 0, 0, 0, 0)),
     "N=256 x 256 (two block rows: one launch)": ((256, 256, 0, None), ("two_block", 1, 0, 0, 0)),
-    "N=384 x 256": ((384, 256, 0, None), ("plain", 1, 0, 0, 0)),
+    "N=384 x 256 (three block rows: one launch)": ((384, 256, 0, None), ("multi_block", 1, 0, 0, 0)),
+    "N=384 x 512": ((384, 512, 0, None), ("plain", 1, 0, 0, 0)),
     "N=64 x 256": ((64, 256, 0, None), ("one_block", 1, 0, 0, 0)),
     "lone N=6900 (look-ahead)": ((6900, 1, 0, None), ("splitk_lookahead", 0, 1, 1, 1)),
 }
