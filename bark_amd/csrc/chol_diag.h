@@ -401,6 +401,59 @@ __device__ __forceinline__ void diag_copy(const double *__restrict__ tile, long 
     }
 }
 
+// The diagonal tile of the one-launch kernels of several block rows (diag_kernel<true, 8>, two_block_kernel<8>, multi_block_kernel), eight waves:
+// D = A_jj (generated) - sum over ALL block rows a < nkb of panel_a' panel_a (diag_update's loop with every block row above instead of
+// the first and the last); the product stages alias S.
+// Eight waves: wave W < 4 takes the entries [0, 5) of UpperBlocks<W>, wave W + 4 the entries [5, 9) — the product is bound by the
+// MFMA pipes of the CU (36 sub-blocks x 32 MFMAs per block row), and four waves left every pipe half idle.
+template <int W, int LO, int HI>
+__device__ __forceinline__ void mb_update(const double *__restrict__ col0, long ld, int nkb, double *lds, double *S, int wave_u, int lane,
+                                          int lr, int lk, const Mats &p, int b, int rep, const uint32_t *codes, int cs, int goff) {
+    using T = UpperBlocks<W>;
+    double pre[9][4];
+    const GenCtx g = gen_ctx(p, b, rep);
+#pragma unroll
+    for (int i = LO; i < HI; ++i) {
+        const int r0 = goff + T::rb[i] * 16 + lk;
+        const int gi[4] = {r0, r0 + 4, r0 + 8, r0 + 12};
+        gen_rows4(g, codes, cs, gi, goff + T::cb[i] * 16 + lr, pre[i]);
+    }
+    f64x4 acc[9];
+#pragma unroll
+    for (int i = LO; i < HI; ++i) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    const int nk = nkb * (NB / BK);  // k-tiles of the whole panel U[0 : 128 nkb, j-block]
+    auto stage = [&](int kt, double *st) {  // wave w moves rows w and w + 8 of the k-tile
+        dma_row(col0 + (size_t)(kt * BK + wave_u) * ld + lane * 2, st + wave_u * LDS_LD);
+        dma_row(col0 + (size_t)(kt * BK + wave_u + 8) * ld + lane * 2, st + (wave_u + 8) * LDS_LD);
+    };
+    if (nk > 0) {
+        stage(0, lds);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) stage(kt + 1, lds + ((kt + 1) & 1) * UPD_STAGE);
+            const double *st = lds + (kt & 1) * UPD_STAGE;
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                double fr[8];
+#pragma unroll
+                for (int blk = 0; blk < 8; ++blk)
+                    if (blk >= W) fr[blk] = st[(kk * 4 + lk) * LDS_LD + blk * 16 + lr];
+#pragma unroll
+                for (int i = LO; i < HI; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[T::rb[i]], fr[T::cb[i]], acc[i], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = LO; i < HI; ++i) {
+        double *blk = S + blk_off(T::rb[i], T::cb[i]);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) blk[(lk + 4 * v) * SB + lr] = pre[i][v] - acc[i][v];
+    }
+}
+
 // G_j = U[j-1,j] W_j for diag_kernel's epilogue (pipelined schedule; W_j upper triangular: column block cbk sums the
 // row blocks rbk <= cbk).  Wave w owns the 16-row blocks 2w, 2w+1 of G.  A fragments (U[j-1,j], 16 rows x 4 columns per
 // MFMA) come straight from L2 — solve(j-1) wrote the tile just before — and the B fragments are the sub-blocks of W_j
@@ -871,7 +924,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void diag_kernel(Mats p, 
         // precedes the writes of S)
         const double *prev = Ab + (size_t)(j - nkb) * NB * p.ld + (size_t)j * NB;  // U[j-nkb, j]
         const int wsel = __builtin_amdgcn_readfirstlane(wave);
-        if (wsel == 0)
+        if (ONE && NW == 8) {  // the one-launch kernel of N <= 128: the tile is generated by all eight waves (nkb == 0: no product loop)
+            switch (wsel) {
+                case 0: mb_update<0, 0, 5>(prev, p.ld, 0, lds, S, wsel, lane, q.lr, q.lk, p, b, ob.rep, codes, NB, 0); break;
+                case 1: mb_update<1, 0, 5>(prev, p.ld, 0, lds, S, wsel, lane, q.lr, q.lk, p, b, ob.rep, codes, NB, 0); break;
+                case 2: mb_update<2, 0, 5>(prev, p.ld, 0, lds, S, wsel, lane, q.lr, q.lk, p, b, ob.rep, codes, NB, 0); break;
+                case 3: mb_update<3, 0, 5>(prev, p.ld, 0, lds, S, wsel, lane, q.lr, q.lk, p, b, ob.rep, codes, NB, 0); break;
+                case 4: mb_update<0, 5, 9>(prev, p.ld, 0, lds, S, wsel, lane, q.lr, q.lk, p, b, ob.rep, codes, NB, 0); break;
+                case 5: mb_update<1, 5, 9>(prev, p.ld, 0, lds, S, wsel, lane, q.lr, q.lk, p, b, ob.rep, codes, NB, 0); break;
+                case 6: mb_update<2, 5, 9>(prev, p.ld, 0, lds, S, wsel, lane, q.lr, q.lk, p, b, ob.rep, codes, NB, 0); break;
+                default: mb_update<3, 5, 9>(prev, p.ld, 0, lds, S, wsel, lane, q.lr, q.lk, p, b, ob.rep, codes, NB, 0); break;
+            }
+        } else if (wsel == 0)
             diag_update<0, ONE>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk, p, b, ob.rep, codes);
         else if (wsel == 1)
             diag_update<1, ONE>(tile, p.ld, prev, nkb, lds, S, lane, q.lr, q.lk, p, b, ob.rep, codes);
@@ -1043,16 +1107,25 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void two_block_kernel(Mat
         constexpr int blk = decltype(BLK)::value;
         double logsum = 0.0, pacc = 1.0;
         int bad = 0;
-        if (wave_u == 0)
+        if (NW == 8) {  // the 36 sub-blocks over eight waves (mb_update); every wave runs the product loop's barriers
+            switch (wave_u) {
+                case 0: mb_update<0, 0, 5>(Ab + NB, p.ld, blk, lds, S, wave_u, lane, lr, lk, p, b, ob.rep, codes, CS, blk * NB); break;
+                case 1: mb_update<1, 0, 5>(Ab + NB, p.ld, blk, lds, S, wave_u, lane, lr, lk, p, b, ob.rep, codes, CS, blk * NB); break;
+                case 2: mb_update<2, 0, 5>(Ab + NB, p.ld, blk, lds, S, wave_u, lane, lr, lk, p, b, ob.rep, codes, CS, blk * NB); break;
+                case 3: mb_update<3, 0, 5>(Ab + NB, p.ld, blk, lds, S, wave_u, lane, lr, lk, p, b, ob.rep, codes, CS, blk * NB); break;
+                case 4: mb_update<0, 5, 9>(Ab + NB, p.ld, blk, lds, S, wave_u, lane, lr, lk, p, b, ob.rep, codes, CS, blk * NB); break;
+                case 5: mb_update<1, 5, 9>(Ab + NB, p.ld, blk, lds, S, wave_u, lane, lr, lk, p, b, ob.rep, codes, CS, blk * NB); break;
+                case 6: mb_update<2, 5, 9>(Ab + NB, p.ld, blk, lds, S, wave_u, lane, lr, lk, p, b, ob.rep, codes, CS, blk * NB); break;
+                default: mb_update<3, 5, 9>(Ab + NB, p.ld, blk, lds, S, wave_u, lane, lr, lk, p, b, ob.rep, codes, CS, blk * NB); break;
+            }
+        } else if (wave_u == 0)
             diag_update<0, true>(nullptr, p.ld, Ab + NB, blk, lds, S, lane, lr, lk, p, b, ob.rep, codes, CS, blk * NB);
         else if (wave_u == 1)
             diag_update<1, true>(nullptr, p.ld, Ab + NB, blk, lds, S, lane, lr, lk, p, b, ob.rep, codes, CS, blk * NB);
         else if (wave_u == 2)
             diag_update<2, true>(nullptr, p.ld, Ab + NB, blk, lds, S, lane, lr, lk, p, b, ob.rep, codes, CS, blk * NB);
-        else if (NW == 4 || wave_u == 3)
+        else
             diag_update<3, true>(nullptr, p.ld, Ab + NB, blk, lds, S, lane, lr, lk, p, b, ob.rep, codes, CS, blk * NB);
-        else  // waves 4-7: the barriers of the update's product loop (diag_update: 1 + 8 for the one block row of the second block)
-            for (int a = blk * (1 + NB / BK); a > 0; --a) __syncthreads();
         __syncthreads();
         TWO_STAMP();
         const int nsb = blk == 0 ? NSB : (p.N - NB + SB - 1) / SB;  // the second block's live sub-blocks; the rest is identity padding
@@ -1129,58 +1202,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void two_block_kernel(Mat
 // ---------------------------------------------------------------------------------------------
 constexpr int MB_MAX_NRB = 4;
 constexpr int MB_STAGE = BK * LDS_LD;  // one operand: 16 rows x (128 + 16) doubles
-
-// D = pre - sum over the block rows a < nkb of panel_a' panel_a on this wave's nine sub-blocks (waves 0-3; diag_update's loop
-// with every block row above instead of the first and the last); the product stages alias S.
-// Eight waves: wave W < 4 takes the entries [0, 5) of UpperBlocks<W>, wave W + 4 the entries [5, 9) — the product is bound by the
-// MFMA pipes of the CU (36 sub-blocks x 32 MFMAs per block row), and four waves left every pipe half idle.
-template <int W, int LO, int HI>
-__device__ __forceinline__ void mb_update(const double *__restrict__ col0, long ld, int nkb, double *lds, double *S, int wave_u, int lane,
-                                          int lr, int lk, const Mats &p, int b, int rep, const uint32_t *codes, int cs, int goff) {
-    using T = UpperBlocks<W>;
-    double pre[9][4];
-    const GenCtx g = gen_ctx(p, b, rep);
-#pragma unroll
-    for (int i = LO; i < HI; ++i) {
-        const int r0 = goff + T::rb[i] * 16 + lk;
-        const int gi[4] = {r0, r0 + 4, r0 + 8, r0 + 12};
-        gen_rows4(g, codes, cs, gi, goff + T::cb[i] * 16 + lr, pre[i]);
-    }
-    f64x4 acc[9];
-#pragma unroll
-    for (int i = LO; i < HI; ++i) acc[i] = (f64x4){0.0, 0.0, 0.0, 0.0};
-    const int nk = nkb * (NB / BK);  // k-tiles of the whole panel U[0 : 128 nkb, j-block]
-    auto stage = [&](int kt, double *st) {  // wave w moves rows w and w + 8 of the k-tile
-        dma_row(col0 + (size_t)(kt * BK + wave_u) * ld + lane * 2, st + wave_u * LDS_LD);
-        dma_row(col0 + (size_t)(kt * BK + wave_u + 8) * ld + lane * 2, st + (wave_u + 8) * LDS_LD);
-    };
-    if (nk > 0) {
-        stage(0, lds);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) stage(kt + 1, lds + ((kt + 1) & 1) * UPD_STAGE);
-            const double *st = lds + (kt & 1) * UPD_STAGE;
-#pragma unroll
-            for (int kk = 0; kk < BK / 4; ++kk) {
-                double fr[8];
-#pragma unroll
-                for (int blk = 0; blk < 8; ++blk)
-                    if (blk >= W) fr[blk] = st[(kk * 4 + lk) * LDS_LD + blk * 16 + lr];
-#pragma unroll
-                for (int i = LO; i < HI; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[T::rb[i]], fr[T::cb[i]], acc[i], 0, 0, 0);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-    }
-#pragma unroll
-    for (int i = LO; i < HI; ++i) {
-        double *blk = S + blk_off(T::rb[i], T::cb[i]);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) blk[(lk + 4 * v) * SB + lr] = pre[i][v] - acc[i][v];
-    }
-}
 
 // Tile (j, c), this wave's 16 columns ct: T, then U[j,c] = W_j' T, stored; y_c -= U' z_j in LDS.  All eight waves (barriers inside).
 // NOT inlined: inside multi_block_kernel's body its 64 + 64 accumulator registers beside the factorisation's spilled ~290 VGPRs;
