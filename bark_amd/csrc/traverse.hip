@@ -154,11 +154,18 @@ constexpr int WALK_GROUPS = 8, WALK_POINTS = WALK_THREADS / WALK_GROUPS;
 // 0.059 | 0.059, N = 256 x 256 0.187 | 0.157 | 0.158 | 0.156, N = 512 x 256 0.554 | 0.522 | 0.515 | 0.530, N = 1024 x 64 1.050 | 1.003 |
 // 1.014 | 1.005, N = 4096 x 16 7.006 | 6.938 | 6.933 | 6.966; N = 64 x 2048 (a grid of 2048) 0.155 | 0.155 | 0.165 | 0.166 — with 8 workgroups
 // per CU the plain kernel hides its chains itself.  Identical integer results (the MLL digests of the A/B agree).
+#ifndef BARK_WALK_NODES_LDS
+#define BARK_WALK_NODES_LDS 1
+#endif
 #ifndef BARK_WALK_GROUPED_MAX_WGS
 #define BARK_WALK_GROUPED_MAX_WGS 2048
 #endif
 constexpr int64_t WALK_GROUPED_MAX_WGS = BARK_WALK_GROUPED_MAX_WGS;  // grids of the one-thread-per-point kernel below this take the grouped one
-template <int MODE>
+// NLDS: the forest's packed nodes (m x stride x 16 bytes: ~9 KB for 50 prior trees) are copied into LDS first and walked
+// there — a thread's six or seven trees are a chain of ~3 dependent node reads each, ~0.5 us apiece from L1 / L2, ~100 cycles
+// from LDS (round 5: the walk was 10 of the 28 us of N = 64 x 256 forests).  Forests too bushy for the LDS left are walked in
+// global memory as before.
+template <int MODE, bool NLDS>
 __global__ __launch_bounds__(WALK_THREADS) void leaf_walk_grouped_kernel(const uint4 *__restrict__ nodes, int stride, int m,
                                                                          int max_depth, const double *__restrict__ X, int N,
                                                                          int d, int npad, int words,
@@ -177,10 +184,15 @@ __global__ __launch_bounds__(WALK_THREADS) void leaf_walk_grouped_kernel(const u
     }
     if (MODE == 2)
         for (int e = tid; e < WALK_POINTS * words; e += WALK_THREADS) acc[e] = 0;
+    const uint4 *forest = nodes + (size_t)b * m * stride;
+    if (NLDS) {  // (16-byte aligned: the X rows and the accumulator words before it are padded to 16 bytes by the launcher)
+        uint4 *ln = reinterpret_cast<uint4 *>(acc + (((MODE == 2 ? WALK_POINTS * words : 0) + 3) & ~3));
+        for (int e = tid; e < m * stride; e += WALK_THREADS) ln[e] = forest[e];
+        forest = ln;
+    }
     __syncthreads();
     const double *xrow = xs + pl * sd;
     const bool live = i < N;
-    const uint4 *forest = nodes + (size_t)b * m * stride;
     if (MODE == 2) {
         if (live) {
             const int t0 = (int)(((long)m * g) / WALK_GROUPS), t1 = (int)(((long)m * (g + 1)) / WALK_GROUPS);
@@ -235,11 +247,18 @@ int launch_walk(const void *packed, const bark_pack_info *info, const double *X,
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint4 *nodes = static_cast<const uint4 *>(packed);
     if constexpr (MODE != 0) {
-        const size_t glds = (size_t)WALK_POINTS * (d | 1) * sizeof(double) + (MODE == 2 ? (size_t)WALK_POINTS * words * sizeof(uint32_t) : 0);
+        // X rows (32 x (d | 1) doubles: a multiple of 16 bytes as 32 doubles are), the accumulator words rounded up to 16 bytes, the nodes
+        const size_t gacc = MODE == 2 ? (((size_t)WALK_POINTS * words + 3) & ~(size_t)3) * sizeof(uint32_t) : 0;
+        const size_t glds = (size_t)WALK_POINTS * (d | 1) * sizeof(double) + gacc;
+        const size_t gnodes = (size_t)info->m * info->stride * sizeof(uint4);
         if ((int64_t)grid.x * grid.y < WALK_GROUPED_MAX_WGS && glds <= 64 * 1024) {  // too few workgroups to hide the chains: share a point's trees out
             const dim3 gg((unsigned)((npad + WALK_POINTS - 1) / WALK_POINTS), (unsigned)info->B);
-            hipLaunchKernelGGL((leaf_walk_grouped_kernel<MODE>), gg, dim3(WALK_THREADS), glds, s, nodes, (int)info->stride,
-                               (int)info->m, (int)info->max_depth, X, (int)N, (int)d, (int)npad, words, out, fault);
+            if (BARK_WALK_NODES_LDS && glds + gnodes <= 32 * 1024)
+                hipLaunchKernelGGL((leaf_walk_grouped_kernel<MODE, true>), gg, dim3(WALK_THREADS), glds + gnodes, s, nodes, (int)info->stride,
+                                   (int)info->m, (int)info->max_depth, X, (int)N, (int)d, (int)npad, words, out, fault);
+            else
+                hipLaunchKernelGGL((leaf_walk_grouped_kernel<MODE, false>), gg, dim3(WALK_THREADS), glds, s, nodes, (int)info->stride,
+                                   (int)info->m, (int)info->max_depth, X, (int)N, (int)d, (int)npad, words, out, fault);
             BARK_LAUNCH_CHECK();
             return BARK_OK;
         }
