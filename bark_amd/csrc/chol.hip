@@ -171,6 +171,9 @@ constexpr int64_t SPLITK_LAYOUT_MAX_WORK = BARK_SPLITK_LAYOUT_MAX_WORK;
 #define BARK_DIAG_WAVES8 1  // chain-bound diag launches (a CU per matrix) with eight waves: factor_tile8
 #endif
 constexpr int DIAG8_MAX_BC = 256;  // one-launch kernels (N <= 256): eight waves up to this many matrices per chunk
+#ifndef BARK_WALK_IN_KERNEL
+#define BARK_WALK_IN_KERNEL 1  // N <= 128 (eight-wave diag_kernel<true>): the leaf walk inside the kernel, no walk launch
+#endif
 #ifndef BARK_TWO_BLOCK
 #define BARK_TWO_BLOCK 1  // 128 < N <= 256, MLL only: the one-launch evaluation by two_block_kernel (0: the multi-launch sweep)
 #endif
@@ -549,8 +552,24 @@ struct Sweep {
 
     // wait_slot: -2 no device-side hand-over; -1 publish the start only; 0 / 1: also wait for that row stream at the end
     // the whole evaluation of a chunk of one-block-row matrices (N <= 128) in one launch: see OneBlock
-    int launch_one_block(const double *y, double *mll, const int32_t *fault, int include_2pi) {
-        const OneBlock ob{y, mll, fault, include_2pi, rep};
+    // N <= 128 with a CU per matrix: the leaf walk runs inside the kernel (OneBlock::nodes) while the points' rows and the forest's
+    // packed nodes fit where the factor image will be
+    bool walk_in_kernel(const bark_pack_info *sub, int64_t d) const {
+        return BARK_WALK_IN_KERNEL && nrb == 1 && BARK_DIAG_WAVES8 && p.Bc <= DIAG8_MAX_BC &&
+               ((size_t)p.N * (d | 1) + 2 + (size_t)sub->m * sub->stride * 2) * sizeof(double) <= (size_t)NBLK * SB * SB * sizeof(double);
+    }
+    int launch_one_block(const double *y, double *mll, int32_t *fault, int include_2pi, const void *packed_c, const bark_pack_info *sub,
+                         const double *X, int64_t d) {
+        OneBlock ob{y, mll, fault, include_2pi, rep};
+        if (walk_in_kernel(sub, d)) {
+            ob.nodes = static_cast<const uint4 *>(packed_c);
+            ob.X = X;
+            ob.fault_w = fault;
+            ob.stride = (int)sub->stride;
+            ob.m = (int)sub->m;
+            ob.max_depth = (int)sub->max_depth;
+            ob.d = (int)d;
+        }
         const size_t lds_bytes = DIAG_LDS + (size_t)p.nW * NB * sizeof(uint32_t);
         // eight waves (factor_tile8) while every matrix of the chunk has a CU to itself; beyond that two four-wave workgroups share one
         const bool w8 = BARK_DIAG_WAVES8 && p.Bc <= DIAG8_MAX_BC;
@@ -1264,10 +1283,9 @@ int bark_mll_batched_hip(bark_ctx *ctx, const void *packed, const bark_pack_info
             p1.scale = use_scale ? scale + c0 : nullptr;
             p1.shift = shift ? shift + c0 : nullptr;
             p1.noise = noise + c0;
-            if ((rc = walk_codes(static_cast<const char *>(packed) + (size_t)c0 * m * info->stride * 16, &sub, X, N, d, leafx, ctx->fault,
-                                 caller)))
-                return rc;
-            if ((rc = sw.launch_one_block(y, mll_out + c0, ctx->fault, (flags & BARK_MLL_INCLUDE_2PI) ? 1 : 0))) return rc;
+            const char *packed_c = static_cast<const char *>(packed) + (size_t)c0 * m * info->stride * 16;
+            if (!sw.walk_in_kernel(&sub, d) && (rc = walk_codes(packed_c, &sub, X, N, d, leafx, ctx->fault, caller))) return rc;
+            if ((rc = sw.launch_one_block(y, mll_out + c0, ctx->fault, (flags & BARK_MLL_INCLUDE_2PI) ? 1 : 0, packed_c, &sub, X, d))) return rc;
             continue;
         }
         sw.paired = plan.paired;

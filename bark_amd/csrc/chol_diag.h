@@ -252,6 +252,12 @@ struct OneBlock {
     double *mll;           // (Bc,) result
     const int32_t *fault;  // the context's categorical-fault flag (set by the leaf walk that precedes this launch)
     int include_2pi, rep;  // MLL convention; leaf-code encoding (LeafRep)
+    // the leaf walk INSIDE the kernel (diag_kernel<true, 8>, round 5): nodes != nullptr — the chunk's packed forests, the points
+    // and the walk's bounds; the codes then never touch global memory and the walk launch in front of the kernel is gone
+    const uint4 *nodes;
+    const double *X;
+    int32_t *fault_w;
+    int stride, m, max_depth, d;
 };
 
 // What every generated entry of matrix b needs besides the two points' codes — read ONCE per kernel phase (gen_ctx): as a
@@ -901,8 +907,49 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void diag_kernel(Mats p, 
     uint32_t *codes = nullptr;
     if (one) {  // the matrix's leaf codes (nW x 128 dwords) behind everything else in LDS
         codes = reinterpret_cast<uint32_t *>(red + 8);
-        const uint32_t *lb = p.leafx + (size_t)b * p.nW * NB;  // npad == 128
-        for (int e = tid; e < p.nW * NB; e += NW * 64) codes[e] = lb[e];
+        if (NW == 8 && ob.nodes) {
+            // ... produced HERE: the points' rows and the forest's packed nodes are staged where the factor image will be, thread
+            // (point t & 127, group t >> 7) walks a quarter of the trees (leaf_walk_grouped_kernel's scheme with four groups),
+            // one-hot bits are OR-ed into the code words in LDS, a byte-code word (four trees) belongs to one group.
+            const int sd = ob.d | 1, nn = ob.m * ob.stride;
+            double *xs = lds;                                                                   // [N][sd]
+            uint4 *ln = reinterpret_cast<uint4 *>(lds + ((p.N * sd + 1) & ~1));                 // [m][stride]
+            for (int e = tid; e < p.N * ob.d; e += NW * 64) {
+                const int r = e / ob.d, c = e - r * ob.d;
+                xs[r * sd + c] = ob.X[e];
+            }
+            const uint4 *forest = ob.nodes + (size_t)b * nn;
+            for (int e = tid; e < nn; e += NW * 64) ln[e] = forest[e];
+            for (int e = tid; e < p.nW * NB; e += NW * 64) codes[e] = 0;
+            __syncthreads();
+            const int pl = tid & (NB - 1), g = tid >> 7;  // four groups of 128 threads
+            if (pl < p.N) {
+                const double *xrow = xs + pl * sd;
+                if (ob.rep == REP_BITS) {
+                    const int t0 = (int)(((long)ob.m * g) / 4), t1 = (int)(((long)ob.m * (g + 1)) / 4);
+                    for (int t = t0; t < t1; ++t) {
+                        const uint32_t bit = walk_tree<true>(ln + (size_t)t * ob.stride, ob.max_depth, xrow, ob.fault_w).z;
+                        const int w = (int)(bit >> 5);
+                        if (w < p.nW) atomicOr(&codes[w * NB + pl], 1u << (bit & 31u));
+                    }
+                } else {
+                    const int W = (ob.m + 3) >> 2;
+                    const int w0 = (int)(((long)W * g) / 4), w1 = (int)(((long)W * (g + 1)) / 4);
+                    for (int w = w0; w < w1; ++w) {
+                        uint32_t word = 0;
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) {
+                            const int t = w * 4 + qq;
+                            if (t < ob.m) word |= (walk_tree<true>(ln + (size_t)t * ob.stride, ob.max_depth, xrow, ob.fault_w).x & 0xFFu) << (8 * qq);
+                        }
+                        codes[w * NB + pl] = word;
+                    }
+                }
+            }
+        } else {
+            const uint32_t *lb = p.leafx + (size_t)b * p.nW * NB;  // npad == 128
+            for (int e = tid; e < p.nW * NB; e += NW * 64) codes[e] = lb[e];
+        }
         __syncthreads();
     }
     double logsum = 0.0;  // sum of log(pivot) / 2 ... (wave 0; pivots_logsum in the last sub-block step)

@@ -104,4 +104,28 @@ __device__ __forceinline__ int agree_count(uint32_t acc, int m) {
     return REP == REP_BITS ? (int)acc : m - (int)acc;
 }
 
+// Root-to-leaf walk of one point through one packed tree (wire format of pack.cpp) — forest.py:28-47 `_pass_one_through_tree`:
+//   categorical:  (1 << int(x[f])) & int(threshold) != 0 -> left ;  otherwise:  x[f] <= float64(float32 threshold) -> left ;
+//   NaN compares false -> right.  Bounded by the packer's max_depth.  Shared by traverse.hip and the one-launch kernel of N <= 128.
+template <bool X_IN_LDS>
+__device__ __forceinline__ uint4 walk_tree(const uint4 *__restrict__ tree, int max_depth, const double *xrow,
+                                           int32_t *__restrict__ fault) {
+    uint4 n = tree[0];
+    for (int step = 0; step < max_depth && !(n.x & LEAF_FLAG); ++step) {
+        const uint32_t f = n.x & FEAT_MASK;
+        const double xv = xrow[f];
+        bool left;
+        if (n.x & CAT_FLAG) {
+            const double xt = trunc(xv);  // int(): toward zero
+            // `1 << int(x)` raises in the reference for NaN / inf / x <= -1 (forest.py:38): flag it, the host raises
+            if (!(xt >= 0.0 && xt < INFINITY)) *fault = 1;
+            left = (xt >= 0.0 && xt < 32.0) ? ((n.y >> (uint32_t)xt) & 1u) : false;
+        } else {
+            left = xv <= (double)__uint_as_float(n.y);
+        }
+        n = tree[left ? n.z : n.w];
+    }
+    return n;
+}
+
 }  // namespace bark

@@ -20,27 +20,6 @@ namespace {
 constexpr int WALK_THREADS = 256;
 constexpr int IDX_CHUNK = 32;  // leaf_walk_kernel MODE 0: trees per staged chunk (one 128-byte segment per point)
 
-template <bool X_IN_LDS>
-__device__ __forceinline__ uint4 walk_tree(const uint4 *__restrict__ tree, int max_depth, const double *xrow,
-                                           int32_t *__restrict__ fault) {
-    uint4 n = tree[0];
-    for (int step = 0; step < max_depth && !(n.x & LEAF_FLAG); ++step) {
-        const uint32_t f = n.x & FEAT_MASK;
-        const double xv = xrow[f];
-        bool left;
-        if (n.x & CAT_FLAG) {
-            const double xt = trunc(xv);  // int(): toward zero
-            // `1 << int(x)` raises in the reference for NaN / inf / x <= -1 (forest.py:38): flag it, the host raises
-            if (!(xt >= 0.0 && xt < INFINITY)) *fault = 1;
-            left = (xt >= 0.0 && xt < 32.0) ? ((n.y >> (uint32_t)xt) & 1u) : false;
-        } else {
-            left = xv <= (double)__uint_as_float(n.y);
-        }
-        n = tree[left ? n.z : n.w];
-    }
-    return n;
-}
-
 // MODE 0: out[b][i][t] = original node index (uint32)   — the reference's (N, m) layout per forest
 // MODE 1: out[b][w][i] = 4 dense leaf ids packed per dword — Gram kernel input, Npad points per plane
 // MODE 2: out[b][w][i] = one-hot code: bit (leaf.z) set for the leaf reached in every tree; W = words.
