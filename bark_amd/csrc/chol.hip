@@ -178,7 +178,10 @@ constexpr int DIAG8_MAX_BC = 256;  // one-launch kernels (N <= 256): eight waves
 #define BARK_TWO_BLOCK 1  // 128 < N <= 256, MLL only: the one-launch evaluation by two_block_kernel (0: the multi-launch sweep)
 #endif
 // ... for chunks of TWO_MIN_BC .. TWO_MAX_BC matrices, and larger chunks up to TWO_ANY_BC_MAX_N points (plan_chunk has the table)
-constexpr int TWO_MIN_BC = 16, TWO_MAX_BC = 384, TWO_ANY_BC_MAX_N = 224;
+#ifndef BARK_TWO_MIN_BC
+#define BARK_TWO_MIN_BC 1
+#endif
+constexpr int TWO_MIN_BC = BARK_TWO_MIN_BC, TWO_MAX_BC = 384, TWO_ANY_BC_MAX_N = 224;
 #ifndef BARK_MULTI_BLOCK
 #define BARK_MULTI_BLOCK 1  // 256 < N <= 512, MLL only: the one-launch evaluation by multi_block_kernel
 #endif
@@ -989,7 +992,8 @@ ChunkPlan plan_chunk(Sweep &sw, int64_t bc, int64_t C, bool timing, bool dev_wai
     // while the codes of 256 points fit behind the factor image in LDS (up to 83 code words per point)
     // ... and while it is the faster form (a workgroup runs its matrix's phases one after the other; the multi-launch sweep spreads a
     // lone matrix over the chip and overlaps the phases of many): round 5, same box, sweep | two_block_kernel, ms —
-    //   N = 256:  x 1..8 0.103-0.105 | 0.107-0.109,  x 256 0.158 | 0.133,  x 512 0.247 | 0.257,  x 1024 0.486 | 0.502,  x 2048 0.88 | 0.96
+    //   N = 256:  x 1..8 0.103-0.105 | 0.107-0.109 (four waves; with eight waves and the tile generation over all of them 0.098 | 0.088: every
+    //             batch size from 1 on since),  x 256 0.158 | 0.133,  x 512 0.247 | 0.257,  x 1024 0.486 | 0.502,  x 2048 0.88 | 0.96
     //   N = 200:  x 32 0.105 | 0.097,  x 256 0.156 | 0.118,  x 512 0.245 | 0.227,  x 1024 0.473 | 0.447      N = 144 x 1024  0.468 | 0.400
     const bool two_ok = nrb == 2 && DIAG_LDS + (size_t)sw.p.nW * 2 * NB * sizeof(uint32_t) + 2 * NB * sizeof(double) <= DIAG_LDS_EXCLUSIVE &&
                         bc >= TWO_MIN_BC && (bc <= TWO_MAX_BC || sw.p.N <= TWO_ANY_BC_MAX_N);

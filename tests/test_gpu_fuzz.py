@@ -15,7 +15,7 @@ CASES = [
     # one block row (N <= 128): the single-launch evaluation (chol.hip OneBlock), incl. chunks and the full 128
     (64, 256, 50, 0, None), (100, 7, 13, 0, None), (128, 40, 50, 0, 16), (20, 3, 50, 0, None), (257, 64, 50, 0, None), (513, 48, 20, 0, 16),
     # two block rows (128 < N <= 256): the single-launch evaluation by two_block_kernel, ragged second blocks, chunks, one matrix
-    # (chunks of 16 .. 384 matrices, more up to N = 224: plan_chunk; the others take the multi-launch sweep)
+    # (chunks of up to 384 matrices, more up to N = 224: plan_chunk; the others take the multi-launch sweep)
     (129, 5, 50, 0, None), (144, 1, 50, 0, None), (200, 256, 50, 0, None), (255, 33, 13, 0, None), (256, 64, 50, 0, 24), (210, 600, 20, 0, None),
     # three / four block rows (256 < N <= 512) in chunks of 160 .. 320 matrices: multi_block_kernel; ragged last blocks, a chunked batch
     (300, 200, 50, 0, None), (400, 170, 13, 0, None), (512, 256, 50, 0, None), (511, 400, 20, 0, 200), (385, 160, 50, 0, None),
@@ -107,9 +107,9 @@ def test_two_block_kernel_against_the_multi_launch_sweep():
 
     assert schedule_plan(200, 64)["schedule"] == "two_block" and schedule_plan(200, 64, timing=True)["schedule"] == "plain"
     assert schedule_plan(200, 64, leaf_words=84)["schedule"] == "plain"  # codes of 256 points no longer fit behind the factor image
-    assert schedule_plan(256, 8)["schedule"] == "plain" and schedule_plan(256, 512)["schedule"] == "plain"  # where the sweep is faster
+    assert schedule_plan(256, 1)["schedule"] == "two_block" and schedule_plan(256, 512)["schedule"] == "plain"  # (where the sweep is faster)
     assert schedule_plan(200, 512)["schedule"] == "two_block" and schedule_plan(256, 300, chunk=256)["last_schedule"] == "two_block"
-    for N, Bn, problem in ((129, 16, "unit"), (177, 40, "unit"), (256, 256, "unit"), (200, 17, "stress"), (240, 32, "mixed")):
+    for N, Bn, problem in ((129, 1, "unit"), (177, 40, "unit"), (256, 256, "unit"), (200, 17, "stress"), (240, 3, "mixed")):
         wl = bench.Workload(N, 8, 50, Bn, seed_base=N, rank_offset=0, problem=problem)
         wl.run()
         torch.cuda.synchronize()

@@ -716,7 +716,7 @@ def test_not_positive_definite_reports_the_first_bad_pivot(B, N, dup, m, eps):
     with pytest.raises(np.linalg.LinAlgError, match="not positive definite") as exc:
         B.fit.batched_mll(F, [noise], None, X, y, ft, include_scale=False, include_2pi=True)
     assert int(re.search(r"pivot (\d+)", str(exc.value)).group(1)) == want, (str(exc.value), want)
-    if 128 < N <= 256:  # ... and through two_block_kernel, which takes chunks of 16 matrices and more: 16 copies of the forest
+    if 128 < N <= 256:  # ... two_block_kernel above (one matrix: eight waves); 16 copies of the forest as well
         from bark_amd.fitting import schedule_plan
 
         assert schedule_plan(N, 16, m=m)["schedule"] == "two_block"

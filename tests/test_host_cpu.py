@@ -373,8 +373,8 @@ def test_schedule_table_of_the_baseline_configs():
         d = schedule_plan(4096, 300, chunk=256)  # a ragged last chunk takes its own schedule
         assert (d["n_chunks"], d["last_chunk"], d["schedule"], d["last_schedule"]) == (2, 44, "paired", "pipelined")
         assert schedule_plan(64, 1, timing=True)["schedule"] == "plain"  # the instrumented call has no one-launch form
-        # two block rows in one launch (round 5): chunks of 16 .. 384 matrices, larger ones up to N = 224; otherwise the sweep
-        assert [schedule_plan(256, b)["schedule"] for b in (1, 15, 16, 384, 385)] == ["plain", "plain", "two_block", "two_block", "plain"]
+        # two block rows in one launch (round 5): chunks of up to 384 matrices, larger ones up to N = 224; otherwise the sweep
+        assert [schedule_plan(256, b)["schedule"] for b in (1, 16, 384, 385)] == ["two_block", "two_block", "two_block", "plain"]
         assert schedule_plan(224, 2048)["schedule"] == "two_block" and schedule_plan(225, 2048)["schedule"] == "plain"
         _lib.lib().bark_device_wait(0)
         assert schedule_plan(1024, 1)["dev_wait"] == 0 and schedule_plan(4096, 8)["dev_gate"] == 0
