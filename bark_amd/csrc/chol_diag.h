@@ -305,17 +305,18 @@ __device__ __forceinline__ void gen_rows4(const GenCtx &g, const uint32_t *codes
         gen_counts4<REP_BYTES8>(codes, cs, g.nW, gi, gj, cnt);
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        double val;
-        if (gi[v] < g.N && gj < g.N) {
-            const int agree = g.rep == REP_BITS ? (int)cnt[v] : g.m - (int)cnt[v];
-            val = g.inv_m * (double)agree;
-            if (g.has_shift) val = val - g.sh;
-            if (g.has_scale) val = g.sc * val;
-            if (gi[v] == gj) val = val + g.jitter;
-        } else {
-            val = gi[v] == gj ? 1.0 : 0.0;  // identity padding
-        }
-        out[v] = val;
+        // (selects, not branches: as if / else every value cost an exec-mask save and restore around a handful of operations)
+        const int agree = g.rep == REP_BITS ? (int)cnt[v] : g.m - (int)cnt[v];
+        double val = g.inv_m * (double)agree;
+        const double shifted = val - g.sh;
+        val = g.has_shift ? shifted : val;
+        const double scaled = g.sc * val;
+        val = g.has_scale ? scaled : val;
+        const double jittered = val + g.jitter;
+        const bool diag = gi[v] == gj;
+        val = diag ? jittered : val;
+        const bool live = gi[v] < g.N && gj < g.N;
+        out[v] = live ? val : (diag ? 1.0 : 0.0);  // identity padding
     }
 }
 
@@ -1250,45 +1251,87 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void two_block_kernel(Mat
 constexpr int MB_MAX_NRB = 4;
 constexpr int MB_STAGE = BK * LDS_LD;  // one operand: 16 rows x (128 + 16) doubles
 
+#ifdef BARK_TWO_STAMPS
+__device__ unsigned long long g_mb_stamps[64];
+#define MBO_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && j == 1 && c == 2) g_mb_stamps[40 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MBO_STAMP(i) do {} while (0)
+#endif
 // Tile (j, c), this wave's 16 columns ct: T, then U[j,c] = W_j' T, stored; y_c -= U' z_j in LDS.  All eight waves (barriers inside).
 // NOT inlined: inside multi_block_kernel's body its 64 + 64 accumulator registers beside the factorisation's spilled ~290 VGPRs;
 // as a function of its own the kernel allocates 248 and spills none.  The LDS arrays arrive as offsets into the kernel's dynamic LDS
 // (pointers through a call would be generic: flat loads instead of ds_read).
-__device__ __attribute__((noinline)) void mb_offdiag(const Mats &p, int b, int rep, int cs, int stage_off, int codes_off, double *Ab, int j,
-                                                     int c, int zj_off, int yc_off, int wave_u, int lane, int lr, int lk) {
+// a wave-uniform value that arrived in vector registers (an argument of a call), back in scalar registers
+__device__ __forceinline__ long uniform_i64(long v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(unsigned long)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((unsigned long)v >> 32));
+    return (long)(((unsigned long)hi << 32) | lo);
+}
+__device__ __forceinline__ double uniform_f64(double v) { return __longlong_as_double(uniform_i64(__double_as_longlong(v))); }
+template <int j>
+__device__ __attribute__((noinline)) void mb_offdiag(GenCtx g, long ld_in, int cs_in, int stage_off, int codes_off, double *Ab_generic,
+                                                     int c_in, int zj_off, int yc_off, int wave_in, int lane, int lr, int lk) {
+    // (arguments of a call arrive in vector registers: the uniform ones go back to scalars — the loop over the code planes in
+    // gen_rows4 is then a scalar loop with scalar address arithmetic instead of an exec-masked one with v_mul_lo_u32 per plane)
+    const int c = __builtin_amdgcn_readfirstlane(c_in);
+    const int cs = __builtin_amdgcn_readfirstlane(cs_in);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave_in);
+    // The matrix's generation constants and stride arrive BY VALUE, the matrix pointer is cast back to global memory.  As first
+    // written the function took `const Mats &p`: the kernel's argument struct then had to live in scratch memory, every use of a
+    // field — here AND in the kernel around the call — became a scratch reload plus a flat access behind an s_waitcnt vmcnt(0),
+    // and the ring below never had two tiles in flight (round 5, profiles/r05/small_n.txt).
+    typedef __attribute__((address_space(1))) double gdouble;
+    gdouble *const Ab = (gdouble *)Ab_generic;
+    const long ld = uniform_i64(ld_in);
+    g.inv_m = uniform_f64(g.inv_m);
+    g.sc = uniform_f64(g.sc);
+    g.sh = uniform_f64(g.sh);
+    g.jitter = uniform_f64(g.jitter);
+    g.rep = __builtin_amdgcn_readfirstlane(g.rep);
+    g.nW = __builtin_amdgcn_readfirstlane(g.nW);
+    g.N = __builtin_amdgcn_readfirstlane(g.N);
+    g.m = __builtin_amdgcn_readfirstlane(g.m);
+    g.has_scale = __builtin_amdgcn_readfirstlane(g.has_scale);
+    g.has_shift = __builtin_amdgcn_readfirstlane(g.has_shift);
     extern __shared__ __attribute__((aligned(16))) double mb_lds[];
     const double *S = mb_lds;
-    double *stage = mb_lds + stage_off;
-    const uint32_t *codes = reinterpret_cast<const uint32_t *>(mb_lds + codes_off);
-    const double *zj = mb_lds + zj_off;
-    double *yc = mb_lds + yc_off;
-    const GenCtx g = gen_ctx(p, b, rep);
+    double *stage = mb_lds + __builtin_amdgcn_readfirstlane(stage_off);
+    const uint32_t *codes = reinterpret_cast<const uint32_t *>(mb_lds + __builtin_amdgcn_readfirstlane(codes_off));
+    const double *zj = mb_lds + __builtin_amdgcn_readfirstlane(zj_off);
+    double *yc = mb_lds + __builtin_amdgcn_readfirstlane(yc_off);
+    MBO_STAMP(0);
     const int ct = wave_u;
     f64x4 tacc[NSB];
 #pragma unroll
     for (int kt = 0; kt < NSB; ++kt) tacc[kt] = (f64x4){0.0, 0.0, 0.0, 0.0};
-    const int nk = j * (NB / BK);
-    if (nk > 0) {  // (workgroup-uniform)
-        const double *Apan = Ab + (size_t)j * NB;                                        // U[0 : 128 j, j-block]: rows k, 128 columns
-        const double *Bcol = Ab + (size_t)c * NB + ct * SB + lr + (size_t)lk * p.ld;     // this lane's B element of row 4 s + lk
-        auto stage_a = [&](int kt, double *st) {  // wave w moves rows w and w + 8 of the k-tile
-            dma_row(Apan + (size_t)(kt * BK + wave_u) * p.ld + lane * 2, st + wave_u * LDS_LD);
-            dma_row(Apan + (size_t)(kt * BK + wave_u + 8) * p.ld + lane * 2, st + (wave_u + 8) * LDS_LD);
-        };
+    constexpr int nk = j * (NB / BK);  // the block step is a template argument: the ring below is straight-line code, every
+                                       // wait a constant (as a run-time loop the joins of its tail conditions cost a vmcnt(0) a tile)
+    if constexpr (nk > 0) {
+        // running pointers (the tiles are issued in order): this wave's two rows of the A k-tile (rows w and w + 8) and this lane's B
+        // element of row 4 s + lk
+        const gdouble *ap = Ab + (size_t)j * NB + (size_t)wave_u * ld + lane * 2;  // U[0 : 128 j, j-block]: rows k, 128 columns
+        const gdouble *bp = Ab + (size_t)c * NB + ct * SB + lr + (size_t)lk * ld;
+        const long ld4 = 4 * ld, ld8 = 8 * ld;
         // ring of three stages, two in flight: the 32 MFMAs of a k-tile are ~2 K cycles a wave, a DMA round trip is more.  The B
         // elements ride in three register sets by the stage's slot (the loop is unrolled by three: no copies of values in flight)
         double bb[3][4];
-        auto issue = [&](int kt, int slot) {  // two DMA rows + four B elements: six VM operations a wave
-            stage_a(kt, stage + slot * MB_STAGE);
+        auto issue = [&](int slot) {  // two DMA rows + four B elements: six VM operations a wave
+            double *st = stage + slot * MB_STAGE;
+            dma_row((const double *)ap, st + wave_u * LDS_LD);
+            dma_row((const double *)(ap + ld8), st + (wave_u + 8) * LDS_LD);
+            ap += 2 * ld8;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) bb[slot][kk] = Bcol[(size_t)(kt * BK + kk * 4) * p.ld];
+            for (int kk = 0; kk < 4; ++kk) {  // (as assembly: the compiler would guard every later use with a vmcnt(0); the counted wait of
+                                              // the step that consumes the slot covers these loads)
+                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(bb[slot][kk]) : "v"(bp) : "memory");
+                bp += ld4;
+            }
         };
         auto step = [&](int kt, int slot) {  // slot == kt % 3, a compile-time constant at every call
             if (kt + 1 < nk)
                 asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (kt + 2 < nk) issue(kt + 2, (slot + 2) % 3);  // that slot was read in iteration kt - 1: every wave is past the barrier
+            if (kt + 2 < nk) issue((slot + 2) % 3);  // that slot was read in iteration kt - 1: every wave is past the barrier
             const double *st = stage + slot * MB_STAGE;
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
@@ -1297,8 +1340,9 @@ __device__ __attribute__((noinline)) void mb_offdiag(const Mats &p, int b, int r
                     tacc[t8] = __builtin_amdgcn_mfma_f64_16x16x4f64(st[(kk * 4 + lk) * LDS_LD + t8 * SB + lr], bb[slot][kk], tacc[t8], 0, 0, 0);
             }
         };
-        issue(0, 0);
-        if (nk > 1) issue(1, 1);
+        issue(0);
+        issue(1);
+#pragma unroll
         for (int kt = 0; kt < nk; kt += 3) {
             step(kt, 0);
             if (kt + 1 < nk) step(kt + 1, 1);
@@ -1306,6 +1350,7 @@ __device__ __attribute__((noinline)) void mb_offdiag(const Mats &p, int b, int r
         }
         __syncthreads();
     }
+    MBO_STAMP(1);
     // T = A_jc - (the sum) in place: tacc[kt] becomes the B fragments of k-tile kt (T[16 kt + 4 kk + lk][16 ct + lr], kk = 0..3)
 #pragma unroll
     for (int kt = 0; kt < NSB; ++kt) {
@@ -1317,9 +1362,13 @@ __device__ __attribute__((noinline)) void mb_offdiag(const Mats &p, int b, int r
         for (int kk = 0; kk < 4; ++kk) tacc[kt][kk] = av[kk] - tacc[kt][kk];
         __builtin_amdgcn_sched_barrier(0);  // one k-tile's generation at a time
     }
+    MBO_STAMP(2);
     f64x4 acc[NSB];
 #pragma unroll
     for (int rt = 0; rt < NSB; ++rt) acc[rt] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    gdouble *U = Ab + (size_t)j * NB * ld + (size_t)c * NB + (size_t)lk * ld + ct * SB + lr;  // this lane's element of row lk
+    const long ld4 = 4 * ld;
+    double sum = 0.0;
 #pragma unroll
     for (int kt = 0; kt < NSB; ++kt) {  // k ascending for every element; W_j is upper triangular: row tiles rt >= kt only
 #pragma unroll
@@ -1331,25 +1380,22 @@ __device__ __attribute__((noinline)) void mb_offdiag(const Mats &p, int b, int r
                     acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(wb[(kk * 4 + lk) * SB + lr], tacc[kt][kk], acc[rt], 0, 0, 0);
             }
         }
-    }
-    double *U = Ab + (size_t)j * NB * p.ld + (size_t)c * NB;
-    double sum = 0.0;
-#pragma unroll
-    for (int rt = 0; rt < NSB; ++rt)
+        // row tile kt is complete (its last k-tile was kt): out it goes while the later row tiles multiply — a CU drains its 128 KB
+        // of stores a tile in ~10 K cycles, which used to follow the product
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const int r = rt * SB + lk + 4 * v;
-            U[(size_t)r * p.ld + ct * SB + lr] = acc[rt][v];
-            sum = fma(acc[rt][v], zj[r], sum);
+            const int r = kt * SB + lk + 4 * v;
+            U[(size_t)(kt * 4 + v) * ld4] = acc[kt][v];
+            sum = fma(acc[kt][v], zj[r], sum);
         }
+    }
+    MBO_STAMP(3);
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
     if (lk == 0) yc[ct * SB + lr] -= sum;
+    MBO_STAMP(4);
 }
 
-#ifdef BARK_TWO_STAMPS
-__device__ unsigned long long g_mb_stamps[64];
-#endif
 __global__ __launch_bounds__(512, 1) void multi_block_kernel(Mats p, OneBlock ob) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, b = blockIdx.x;
@@ -1380,6 +1426,7 @@ __global__ __launch_bounds__(512, 1) void multi_block_kernel(Mats p, OneBlock ob
 #define MB_STAMP() do {} while (0)
 #endif
     MB_STAMP();
+    const GenCtx gctx = gen_ctx(p, b, ob.rep);
     // (a block step per compile-time index: as a run-time loop the body — mb_update, factor_tile8, mb_offdiag — spilled 150 VGPRs)
     auto block = [&](auto JJ) {
         constexpr int j = decltype(JJ)::value;
@@ -1436,10 +1483,14 @@ __global__ __launch_bounds__(512, 1) void multi_block_kernel(Mats p, OneBlock ob
         MB_STAMP();
 #pragma unroll 1
         for (int c = j + 1; c < nrb; ++c) {
-            mb_offdiag(p, b, ob.rep, cs, (int)(stage - lds), (int)(reinterpret_cast<double *>(codes) - lds), Ab, j, c,
-                       (int)(zlds - lds) + j * NB, (int)(ylds - lds) + c * NB, wave_u, lane, lr, lk);
-            __syncthreads();  // U[j,c] (global: this workgroup's own stores) and y_c are visible to every wave
+            // (no barrier between the tiles of a block row: a tile reads none of its predecessor's results, and its first write to a
+            // stage slot comes after this wave passed the barrier that ended the predecessor's GEMM.  The call itself begins with an
+            // s_waitcnt vmcnt(0): with the c loop inside the function the stores could drain under the next tile, but that
+            // body spills 78 VGPRs)
+            mb_offdiag<j>(gctx, p.ld, cs, (int)(stage - lds), (int)(reinterpret_cast<double *>(codes) - lds), Ab, c,
+                          (int)(zlds - lds) + j * NB, (int)(ylds - lds) + c * NB, wave_u, lane, lr, lk);
         }
+        __syncthreads();  // U[j, :] (global: this workgroup's own stores) and y are visible to every wave
         MB_STAMP();
     };
     block(std::integral_constant<int, 0>{});

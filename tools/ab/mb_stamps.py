@@ -17,3 +17,4 @@ nrb = (N + 127) // 128
 names = ["start"] + [f"j={j} {w}" for j in range(nrb) for w in ("assembled", "factored", "z", "off-diagonal tiles")]
 for i, n in enumerate(names):
     print(f"{n:26s} {t[i] - t[0]:9d} cyc (+{t[i] - t[max(i - 1, 0)]:7d})")
+print("mb_offdiag (j = 1, c = 2), thread 0:", "GEMM K=128", t[41] - t[40], "| T = gen - sum", t[42] - t[41], "| product", t[43] - t[42], "| store + y", t[44] - t[43])
