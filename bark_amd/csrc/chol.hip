@@ -185,17 +185,20 @@ constexpr int TWO_MIN_BC = BARK_TWO_MIN_BC, TWO_MAX_BC = 384, TWO_ANY_BC_MAX_N =
 #ifndef BARK_MULTI_BLOCK
 #define BARK_MULTI_BLOCK 1  // 256 < N <= 512, MLL only: the one-launch evaluation by multi_block_kernel
 #endif
-// Chunks of MB_MIN_BC .. MB_MAX_BC matrices: the kernel runs a matrix's block steps one after the other on ONE CU (~0.38 ms at N = 512
-// whatever the batch), the sweep spreads a matrix over the chip — round 5, same box, sweep | multi_block_kernel, ms:
-//   N = 512:  x 16 0.20 | 0.38,  x 64 0.30 | 0.42,  x 96 0.35 | 0.41,  x 128 0.38 | 0.42,  x 192 0.47 | 0.44,  x 256 0.52 | 0.46,  x 384 0.82 | 0.86
-//   N = 384:  x 128 0.216 | 0.227,  x 256 0.298 | 0.252        N = 300:  x 64 0.190 | 0.198,  x 128 0.214 | 0.209,  x 256 0.292 | 0.230
-#ifndef BARK_MB_MIN_BC
-#define BARK_MB_MIN_BC 160
+// Chunks of at least MB_MIN_BC4 (four block rows) / MB_MIN_BC3 (three) matrices: the kernel runs a matrix's block steps one after the
+// other on ONE CU (~0.35 ms at N = 512 whatever the batch), the sweep spreads a matrix over the chip.  Round 5, same box, one process per
+// variant, sweep | multi_block_kernel, ms (with the kernel's three-stage ring really in flight; before that the window was 160 .. 320):
+//   N = 512:  x 64 0.282 | 0.347,  x 80 0.313 | 0.348,  x 96 0.343 | 0.348,  x 112 0.370 | 0.351,  x 128 0.365 | 0.350,  x 256 0.44-0.52 | 0.385,
+//             x 384 0.782 | 0.720,  x 512 0.901 | 0.786,  x 768 1.345 | 1.180,  x 1024 1.741 | 1.588,  x 2048 3.336 | 3.135,  x 4096 6.402 | 6.181
+//   N = 384:  x 64 0.187 | 0.193,  x 96 0.202 | 0.199,  x 128 0.210 | 0.200,  x 384 0.440 | 0.402,  x 512 0.512 | 0.410,  x 1000 1.024 | 0.821
+//   N = 300:  x 16 0.152 | 0.166,  x 32 0.177 | 0.168,  x 64 0.186 | 0.178,  x 128 0.207 | 0.185,  x 512 0.496 | 0.382,  x 2048 1.863 | 1.588
+#ifndef BARK_MB_MIN_BC4
+#define BARK_MB_MIN_BC4 112
 #endif
-#ifndef BARK_MB_MAX_BC
-#define BARK_MB_MAX_BC 320
+#ifndef BARK_MB_MIN_BC3
+#define BARK_MB_MIN_BC3 80
 #endif
-constexpr int MB_MIN_BC = BARK_MB_MIN_BC, MB_MAX_BC = BARK_MB_MAX_BC;
+constexpr int MB_MIN_BC4 = BARK_MB_MIN_BC4, MB_MIN_BC3 = BARK_MB_MIN_BC3;
 // dynamic LDS of multi_block_kernel: factor image, vec, red, y and z (four blocks each), three A-panel stages, the leaf codes
 inline size_t mb_lds_bytes(int nW, int nrb) {
     return (size_t)(NBLK * SB * SB + 2 * NB + 8 + 2 * MB_MAX_NRB * NB + 3 * MB_STAGE) * sizeof(double) + (size_t)nW * nrb * NB * sizeof(uint32_t);
@@ -1000,7 +1003,7 @@ ChunkPlan plan_chunk(Sweep &sw, int64_t bc, int64_t C, bool timing, bool dev_wai
     c.one_block = (nrb == 1 || (BARK_TWO_BLOCK && two_ok)) && sw.fused && C == 0 && !timing;
     // 256 < N <= 512: multi_block_kernel (three or four block rows in one launch, eight waves), whatever layout the sweep would
     // take for the chunk, while the codes of the matrix's points fit beside the factor image and the GEMM stages in LDS
-    if (BARK_MULTI_BLOCK && (nrb == 3 || nrb == 4) && C == 0 && !timing && bc >= MB_MIN_BC && bc <= MB_MAX_BC &&
+    if (BARK_MULTI_BLOCK && (nrb == 3 || nrb == 4) && C == 0 && !timing && bc >= (nrb == 4 ? MB_MIN_BC4 : MB_MIN_BC3) &&
         mb_lds_bytes(sw.p.nW, nrb) <= DIAG_LDS_EXCLUSIVE)
         c.one_block = true;
     sw.p.Bc = (int)bc;  // lookahead() / split_factor() read the chunk size

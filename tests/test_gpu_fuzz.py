@@ -17,7 +17,7 @@ CASES = [
     # two block rows (128 < N <= 256): the single-launch evaluation by two_block_kernel, ragged second blocks, chunks, one matrix
     # (chunks of up to 384 matrices, more up to N = 224: plan_chunk; the others take the multi-launch sweep)
     (129, 5, 50, 0, None), (144, 1, 50, 0, None), (200, 256, 50, 0, None), (255, 33, 13, 0, None), (256, 64, 50, 0, 24), (210, 600, 20, 0, None),
-    # three / four block rows (256 < N <= 512) in chunks of 160 .. 320 matrices: multi_block_kernel; ragged last blocks, a chunked batch
+    # three / four block rows (256 < N <= 512) in chunks of at least 80 / 112 matrices: multi_block_kernel; ragged last blocks, a chunked batch
     (300, 200, 50, 0, None), (400, 170, 13, 0, None), (512, 256, 50, 0, None), (511, 400, 20, 0, 200), (385, 160, 50, 0, None),
     (700, 100, 13, 0, None), (777, 33, 50, 0, None), (900, 12, 50, 0, None), (1100, 64, 50, 0, None),
     (1300, 40, 30, 0, 24), (1500, 9, 50, 0, None), (2100, 2, 50, 0, None), (2500, 20, 50, 0, None),
@@ -129,7 +129,7 @@ def test_two_block_kernel_against_the_multi_launch_sweep():
 
 
 def test_multi_block_kernel_against_the_multi_launch_sweep():
-    """256 < N <= 512 (round 5): `multi_block_kernel` evaluates a chunk of 160 .. 320 matrices in one launch after the leaf walk —
+    """256 < N <= 512 (round 5): `multi_block_kernel` evaluates a chunk of at least 80 (three block rows) / 112 (four) matrices in one launch after the leaf walk —
     three or four block rows, the off-diagonal GEMMs in the same workgroup.  Against the sweep it replaces (the instrumented call takes
     the multi-launch schedule) to 1e-12 relative, against the oracle's LU route, with byte codes (bushy forests), and the index of a
     non-positive pivot in the second, third and fourth block."""
@@ -144,7 +144,8 @@ def test_multi_block_kernel_against_the_multi_launch_sweep():
     from oracle import oracle as orc
 
     assert schedule_plan(512, 256)["schedule"] == "multi_block" and schedule_plan(300, 160)["schedule"] == "multi_block"
-    assert schedule_plan(512, 64)["schedule"] != "multi_block" and schedule_plan(512, 400)["schedule"] == "plain"
+    assert schedule_plan(512, 64)["schedule"] != "multi_block" and schedule_plan(512, 400)["schedule"] == "multi_block"
+    assert schedule_plan(384, 64)["schedule"] != "multi_block" and schedule_plan(384, 80)["schedule"] == "multi_block"
     assert schedule_plan(512, 256, timing=True)["schedule"] == "plain" and schedule_plan(512, 256, leaf_words=40)["schedule"] == "plain"
     for N, Bn, problem in ((257, 160, "unit"), (384, 200, "unit"), (512, 256, "unit"), (380, 161, "stress"), (500, 170, "mixed")):
         wl = bench.Workload(N, 8, 50, Bn, seed_base=N, rank_offset=0, problem=problem)
