@@ -147,7 +147,9 @@ def test_multi_block_kernel_against_the_multi_launch_sweep():
     assert schedule_plan(512, 64)["schedule"] != "multi_block" and schedule_plan(512, 400)["schedule"] == "multi_block"
     assert schedule_plan(384, 64)["schedule"] != "multi_block" and schedule_plan(384, 80)["schedule"] == "multi_block"
     assert schedule_plan(512, 256, timing=True)["schedule"] == "plain" and schedule_plan(512, 256, leaf_words=40)["schedule"] == "plain"
-    for N, Bn, problem in ((257, 160, "unit"), (384, 200, "unit"), (512, 256, "unit"), (380, 161, "stress"), (500, 170, "mixed")):
+    # (… and the ends of the window: the smallest chunks that take the kernel, one of more matrices than the chip has CUs)
+    for N, Bn, problem in ((257, 160, "unit"), (384, 200, "unit"), (512, 256, "unit"), (380, 161, "stress"), (500, 170, "mixed"),
+                           (512, 112, "unit"), (300, 80, "unit"), (300, 600, "unit")):
         wl = bench.Workload(N, 8, 50, Bn, seed_base=N, rank_offset=0, problem=problem)
         words = int(_lib.lib().bark_leaf_words(wl.pf.info_ref))  # 5 for prior forests, 13 (bytes) for the bushy ones: three block rows only
         assert schedule_plan(N, Bn, leaf_words=words)["schedule"] == "multi_block", (N, Bn, words)
