@@ -183,7 +183,7 @@ constexpr int DIAG8_MAX_BC = 256;  // one-launch kernels (N <= 256): eight waves
 #endif
 constexpr int TWO_MIN_BC = BARK_TWO_MIN_BC, TWO_MAX_BC = 384, TWO_ANY_BC_MAX_N = 224;
 #ifndef BARK_MULTI_BLOCK
-#define BARK_MULTI_BLOCK 1  // 256 < N <= 512, MLL only: the one-launch evaluation by multi_block_kernel
+#define BARK_MULTI_BLOCK 1  // 256 < N <= 768, MLL only: the one-launch evaluation by multi_block_kernel
 #endif
 // Chunks of at least MB_MIN_BC4 (four block rows) / MB_MIN_BC3 (three) matrices: the kernel runs a matrix's block steps one after the
 // other on ONE CU (~0.35 ms at N = 512 whatever the batch), the sweep spreads a matrix over the chip.  Round 5, same box, one process per
@@ -198,10 +198,26 @@ constexpr int TWO_MIN_BC = BARK_TWO_MIN_BC, TWO_MAX_BC = 384, TWO_ANY_BC_MAX_N =
 #ifndef BARK_MB_MIN_BC3
 #define BARK_MB_MIN_BC3 80
 #endif
-constexpr int MB_MIN_BC4 = BARK_MB_MIN_BC4, MB_MIN_BC3 = BARK_MB_MIN_BC3;
-// dynamic LDS of multi_block_kernel: factor image, vec, red, y and z (four blocks each), three A-panel stages, the leaf codes
+// FIVE and SIX block rows (512 < N <= 768; forests whose leaf codes fit: 7 / 6 words a point — the one-hot codes of prior-sized trees), same
+// box, sweep | multi_block_kernel, ms: a matrix now holds its CU for 0.58 / 0.90 ms, so the chunk must nearly fill whole rounds of the 256 CUs
+//   N = 640:  x 128 0.527 | 0.584   x 160 0.633 | 0.601   x 192 0.788 | 0.625   x 224 0.819 | 0.649   x 256 0.826 | 0.673   x 384 1.266 | 1.253
+//             x 512 1.497 | 1.317   x 2048 5.474 | 5.229
+//   N = 768:  x 128 0.784 | 0.903   x 160 0.982 | 0.933   x 192 1.081 | 0.954   x 224 1.190 | 0.998   x 256 1.197 | 1.015   x 384 1.886 | 1.959
+//             x 512 2.234 | 2.051   x 1024 4.347 | 4.069          N = 600 x 256 0.814 | 0.666      N = 700 x 1024 4.246 | 3.990
+#ifndef BARK_MB_MIN_BC5
+#define BARK_MB_MIN_BC5 144
+#endif
+constexpr int MB_MIN_BC4 = BARK_MB_MIN_BC4, MB_MIN_BC3 = BARK_MB_MIN_BC3, MB_MIN_BC5 = BARK_MB_MIN_BC5;
+constexpr int MB_CUS = 256;  // ... five / six block rows: at least 80 % of ceil(chunk / CUs) rounds filled
+inline bool mb_chunk_ok(int nrb, int64_t bc) {
+    if (nrb <= 3) return bc >= MB_MIN_BC3;
+    if (nrb == 4) return bc >= MB_MIN_BC4;
+    const int64_t rounds = (bc + MB_CUS - 1) / MB_CUS;
+    return bc >= MB_MIN_BC5 && (rounds == 1 || bc * 5 >= rounds * MB_CUS * 4);
+}
+// dynamic LDS of multi_block_kernel: factor image, vec, red, y and z (a block per block row of the matrix each), three A-panel stages, the leaf codes
 inline size_t mb_lds_bytes(int nW, int nrb) {
-    return (size_t)(NBLK * SB * SB + 2 * NB + 8 + 2 * MB_MAX_NRB * NB + 3 * MB_STAGE) * sizeof(double) + (size_t)nW * nrb * NB * sizeof(uint32_t);
+    return (size_t)(NBLK * SB * SB + 2 * NB + 8 + 2 * nrb * NB + 3 * MB_STAGE) * sizeof(double) + (size_t)nW * nrb * NB * sizeof(uint32_t);
 }
 #ifndef BARK_PIPE_MIN_NRB
 #define BARK_PIPE_MIN_NRB 8
@@ -579,7 +595,7 @@ struct Sweep {
         const size_t lds_bytes = DIAG_LDS + (size_t)p.nW * NB * sizeof(uint32_t);
         // eight waves (factor_tile8) while every matrix of the chunk has a CU to itself; beyond that two four-wave workgroups share one
         const bool w8 = BARK_DIAG_WAVES8 && p.Bc <= DIAG8_MAX_BC;
-        if (nrb >= 3) {  // multi_block_kernel (256 < N <= 512)
+        if (nrb >= 3) {  // multi_block_kernel (256 < N <= 768)
             hipLaunchKernelGGL(multi_block_kernel, dim3((unsigned)p.Bc), dim3(512), mb_lds_bytes(p.nW, nrb), main, p, ob);
         } else if (nrb == 2) {  // two_block_kernel: codes of 256 points + z_0 + U_01' z_0 behind the factor image
             const size_t lds2 = DIAG_LDS + (size_t)p.nW * 2 * NB * sizeof(uint32_t) + 2 * NB * sizeof(double);
@@ -1001,9 +1017,9 @@ ChunkPlan plan_chunk(Sweep &sw, int64_t bc, int64_t C, bool timing, bool dev_wai
     const bool two_ok = nrb == 2 && DIAG_LDS + (size_t)sw.p.nW * 2 * NB * sizeof(uint32_t) + 2 * NB * sizeof(double) <= DIAG_LDS_EXCLUSIVE &&
                         bc >= TWO_MIN_BC && (bc <= TWO_MAX_BC || sw.p.N <= TWO_ANY_BC_MAX_N);
     c.one_block = (nrb == 1 || (BARK_TWO_BLOCK && two_ok)) && sw.fused && C == 0 && !timing;
-    // 256 < N <= 512: multi_block_kernel (three or four block rows in one launch, eight waves), whatever layout the sweep would
+    // 256 < N <= 768: multi_block_kernel (three to six block rows in one launch, eight waves), whatever layout the sweep would
     // take for the chunk, while the codes of the matrix's points fit beside the factor image and the GEMM stages in LDS
-    if (BARK_MULTI_BLOCK && (nrb == 3 || nrb == 4) && C == 0 && !timing && bc >= (nrb == 4 ? MB_MIN_BC4 : MB_MIN_BC3) &&
+    if (BARK_MULTI_BLOCK && nrb >= 3 && nrb <= MB_MAX_NRB && C == 0 && !timing && mb_chunk_ok(nrb, bc) &&
         mb_lds_bytes(sw.p.nW, nrb) <= DIAG_LDS_EXCLUSIVE)
         c.one_block = true;
     sw.p.Bc = (int)bc;  // lookahead() / split_factor() read the chunk size

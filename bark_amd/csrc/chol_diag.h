@@ -1232,7 +1232,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void two_block_kernel(Mat
 }
 
 // ---------------------------------------------------------------------------------------------
-// multi_block_kernel (round 5): matrices of THREE or FOUR block rows (256 < N <= 512) in one launch, eight waves, one workgroup
+// multi_block_kernel (round 5): matrices of THREE to SIX block rows (256 < N <= 768) in one launch, eight waves, one workgroup
 // per matrix — two_block_kernel's scheme with the off-diagonal GEMMs in the same workgroup.  The multi-launch sweep of 256
 // such matrices moves every tile through HBM three times (T written by the row launch, read and rewritten as U by the solve,
 // read as a panel by the next row launch: 0.5 GB per pass against 36 MB of L2) and takes 0.52 ms at N = 512; a CU's own MFMA
@@ -1248,7 +1248,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void two_block_kernel(Mat
 // U tiles go to the workspace (L2-resident scratch); nothing else leaves the CU until the MLL.  Per element the k order of every
 // sum is ascending as in the sweep; the right-hand-side update sums in two_block_kernel's order.
 // ---------------------------------------------------------------------------------------------
-constexpr int MB_MAX_NRB = 4;
+constexpr int MB_MAX_NRB = 6;  // block rows of a matrix in multi_block_kernel (LDS: y and z by the matrix's OWN count, the codes of all its points)
 constexpr int MB_STAGE = BK * LDS_LD;  // one operand: 16 rows x (128 + 16) doubles
 
 #ifdef BARK_TWO_STAMPS
@@ -1408,8 +1408,8 @@ __global__ __launch_bounds__(512, 1) void multi_block_kernel(Mats p, OneBlock ob
     double *vec = lds + NBLK * SB * SB;     // [2][128] y | upper-half partial sums
     double *red = vec + 2 * NB;             // [8]
     double *ylds = red + 8;                 // [nrb][128] the right-hand side, updated in place
-    double *zlds = ylds + MB_MAX_NRB * NB;  // [nrb][128] z_j
-    double *stage = zlds + MB_MAX_NRB * NB; // [3][16][LDS_LD] A panel stages of the off-diagonal GEMMs (a ring)
+    double *zlds = ylds + nrb * NB;         // [nrb][128] z_j
+    double *stage = zlds + nrb * NB;        // [3][16][LDS_LD] A panel stages of the off-diagonal GEMMs (a ring)
     uint32_t *codes = reinterpret_cast<uint32_t *>(stage + 3 * MB_STAGE);  // [nW][cs]
     {
         const uint32_t *lb = p.leafx + (size_t)b * p.nW * cs;
@@ -1497,6 +1497,8 @@ __global__ __launch_bounds__(512, 1) void multi_block_kernel(Mats p, OneBlock ob
     block(std::integral_constant<int, 1>{});
     block(std::integral_constant<int, 2>{});
     block(std::integral_constant<int, 3>{});
+    block(std::integral_constant<int, 4>{});
+    block(std::integral_constant<int, 5>{});
     if (tid == 0) {  // finish_mll_kernel's arithmetic (quick_inverse.py:38 / mcmc_record_mll.py:73)
         double v = -quad_sum - 2.0 * logsum_sum;
         if (ob.include_2pi) v = v - (double)p.N * log(2.0 * M_PI);

@@ -235,7 +235,7 @@ enum {
     BARK_SCHED_SPLITK = 4,           /* split-K layout (A materialised, slab scratch), no look-ahead step */
     BARK_SCHED_SPLITK_LOOKAHEAD = 5, /* split-K layout with look-ahead bulk launches */
     BARK_SCHED_TWO_BLOCK = 6,        /* 128 < N <= 256, MLL only: leaf walk + one launch per chunk (two block rows in one kernel) */
-    BARK_SCHED_MULTI_BLOCK = 7       /* 256 < N <= 512, MLL only: the same with three or four block rows */
+    BARK_SCHED_MULTI_BLOCK = 7       /* 256 < N <= 768, MLL only: the same with three to six block rows */
 };
 typedef struct {
     int32_t n_chunks, chunk, last_chunk;  /* chunks of `chunk` matrices, the last one of `last_chunk` */

@@ -19,6 +19,8 @@ CASES = [
     (129, 5, 50, 0, None), (144, 1, 50, 0, None), (200, 256, 50, 0, None), (255, 33, 13, 0, None), (256, 64, 50, 0, 24), (210, 600, 20, 0, None),
     # three / four block rows (256 < N <= 512) in chunks of at least 80 / 112 matrices: multi_block_kernel; ragged last blocks, a chunked batch
     (300, 200, 50, 0, None), (400, 170, 13, 0, None), (512, 256, 50, 0, None), (511, 400, 20, 0, 200), (385, 160, 50, 0, None),
+    # five / six block rows (512 < N <= 768) in chunks of at least 144 matrices that nearly fill whole rounds of the CUs: the same kernel
+    (640, 160, 50, 0, None), (768, 256, 50, 0, None), (601, 150, 20, 0, None), (700, 520, 13, 0, 260),
     (700, 100, 13, 0, None), (777, 33, 50, 0, None), (900, 12, 50, 0, None), (1100, 64, 50, 0, None),
     (1300, 40, 30, 0, 24), (1500, 9, 50, 0, None), (2100, 2, 50, 0, None), (2500, 20, 50, 0, None),
     (640, 16, 50, 90, None), (1000, 70, 25, 130, None), (1400, 3, 50, 300, None),
@@ -129,8 +131,8 @@ def test_two_block_kernel_against_the_multi_launch_sweep():
 
 
 def test_multi_block_kernel_against_the_multi_launch_sweep():
-    """256 < N <= 512 (round 5): `multi_block_kernel` evaluates a chunk of at least 80 (three block rows) / 112 (four) matrices in one launch after the leaf walk —
-    three or four block rows, the off-diagonal GEMMs in the same workgroup.  Against the sweep it replaces (the instrumented call takes
+    """256 < N <= 768 (round 5): `multi_block_kernel` evaluates a chunk of at least 80 (three block rows) / 112 (four) / 144 (five, six) matrices in one launch after the leaf walk —
+    three to six block rows, the off-diagonal GEMMs in the same workgroup.  Against the sweep it replaces (the instrumented call takes
     the multi-launch schedule) to 1e-12 relative, against the oracle's LU route, with byte codes (bushy forests), and the index of a
     non-positive pivot in the second, third and fourth block."""
     import re
@@ -146,10 +148,14 @@ def test_multi_block_kernel_against_the_multi_launch_sweep():
     assert schedule_plan(512, 256)["schedule"] == "multi_block" and schedule_plan(300, 160)["schedule"] == "multi_block"
     assert schedule_plan(512, 64)["schedule"] != "multi_block" and schedule_plan(512, 400)["schedule"] == "multi_block"
     assert schedule_plan(384, 64)["schedule"] != "multi_block" and schedule_plan(384, 80)["schedule"] == "multi_block"
+    # five / six block rows: from 144 matrices, and only chunks that fill at least 80 % of their rounds of 256 CUs
+    assert schedule_plan(768, 128)["schedule"] != "multi_block" and schedule_plan(768, 144)["schedule"] == "multi_block"
+    assert schedule_plan(640, 384)["schedule"] != "multi_block" and schedule_plan(640, 512)["schedule"] == "multi_block"
+    assert schedule_plan(769, 256)["schedule"] != "multi_block" and schedule_plan(768, 256, leaf_words=7)["schedule"] != "multi_block"
     assert schedule_plan(512, 256, timing=True)["schedule"] == "plain" and schedule_plan(512, 256, leaf_words=40)["schedule"] == "plain"
     # (… and the ends of the window: the smallest chunks that take the kernel, one of more matrices than the chip has CUs)
     for N, Bn, problem in ((257, 160, "unit"), (384, 200, "unit"), (512, 256, "unit"), (380, 161, "stress"), (500, 170, "mixed"),
-                           (512, 112, "unit"), (300, 80, "unit"), (300, 600, "unit")):
+                           (512, 112, "unit"), (300, 80, "unit"), (300, 600, "unit"), (640, 144, "unit"), (768, 256, "unit"), (700, 150, "unit")):
         wl = bench.Workload(N, 8, 50, Bn, seed_base=N, rank_offset=0, problem=problem)
         words = int(_lib.lib().bark_leaf_words(wl.pf.info_ref))  # 5 for prior forests, 13 (bytes) for the bushy ones: three block rows only
         assert schedule_plan(N, Bn, leaf_words=words)["schedule"] == "multi_block", (N, Bn, words)

@@ -5,7 +5,7 @@ OUT=$ROOT/gpurun_out/prof_${1:-r05}
 mkdir -p $OUT
 export PYTHONPATH=$ROOT
 python3 bench.py > $OUT/bench_c3_final.json 2> $OUT/bench.err || { echo bench failed; tail -5 $OUT/bench.err; exit 1; }
-for spec in "c3 4096 256 2" "b64 4096 64 3" "b16 4096 16 3" "b8 4096 8 3" "b1 4096 1 5" "c2 1024 1 10" "c5 16384 1 2" "c5_posterior 16384 1 1 10000" "n64 64 256 10" "n128 128 256 10" "n256 256 256 10" "n512 512 256 10"; do
+for spec in "c3 4096 256 2" "b64 4096 64 3" "b16 4096 16 3" "b8 4096 8 3" "b1 4096 1 5" "c2 1024 1 10" "c5 16384 1 2" "c5_posterior 16384 1 1 10000" "n64 64 256 10" "n128 128 256 10" "n256 256 256 10" "n512 512 256 10" "n768 768 256 10"; do
   set -- $spec; label=$1; shift
   tools/kernel_trace.sh $label product "$@" > /dev/null || exit 1
   cp gpurun_out/trace_$label.txt $OUT/trace_$label.txt
