@@ -208,12 +208,16 @@ constexpr int TWO_MIN_BC = BARK_TWO_MIN_BC, TWO_MAX_BC = 384, TWO_ANY_BC_MAX_N =
 #define BARK_MB_MIN_BC5 144
 #endif
 constexpr int MB_MIN_BC4 = BARK_MB_MIN_BC4, MB_MIN_BC3 = BARK_MB_MIN_BC3, MB_MIN_BC5 = BARK_MB_MIN_BC5;
-constexpr int MB_CUS = 256;  // ... five / six block rows: at least 80 % of ceil(chunk / CUs) rounds filled
+// Chunks of more matrices than CUs run in rounds, and a round that is mostly empty costs a whole matrix time: sweep | kernel, ms —
+//   N = 512:  x 272 0.621 | 0.717   x 300 0.643 | 0.722   x 320 0.664 | 0.723   x 352 0.733 | 0.723   x 544 1.117 | 1.102   x 600 1.169 | 1.104
+//   N = 384:  x 272 0.357 | 0.400   x 300 0.376 | 0.398   x 340 0.397 | 0.403          N = 300:  x 272 0.354 | 0.370   x 320 0.371 | 0.373
+// -> beyond one round only chunks that fill at least 70 % (five / six block rows: 80 %) of ceil(chunk / CUs) rounds
+constexpr int MB_CUS = 256;
 inline bool mb_chunk_ok(int nrb, int64_t bc) {
-    if (nrb <= 3) return bc >= MB_MIN_BC3;
-    if (nrb == 4) return bc >= MB_MIN_BC4;
     const int64_t rounds = (bc + MB_CUS - 1) / MB_CUS;
-    return bc >= MB_MIN_BC5 && (rounds == 1 || bc * 5 >= rounds * MB_CUS * 4);
+    if (bc < (nrb <= 3 ? MB_MIN_BC3 : nrb == 4 ? MB_MIN_BC4 : MB_MIN_BC5)) return false;
+    if (rounds <= 1) return true;
+    return nrb <= 4 ? bc * 10 >= rounds * MB_CUS * 7 : bc * 5 >= rounds * MB_CUS * 4;
 }
 // dynamic LDS of multi_block_kernel: factor image, vec, red, y and z (a block per block row of the matrix each), three A-panel stages, the leaf codes
 inline size_t mb_lds_bytes(int nW, int nrb) {

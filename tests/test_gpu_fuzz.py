@@ -149,6 +149,7 @@ def test_multi_block_kernel_against_the_multi_launch_sweep():
     assert schedule_plan(512, 64)["schedule"] != "multi_block" and schedule_plan(512, 400)["schedule"] == "multi_block"
     assert schedule_plan(384, 64)["schedule"] != "multi_block" and schedule_plan(384, 80)["schedule"] == "multi_block"
     # five / six block rows: from 144 matrices, and only chunks that fill at least 80 % of their rounds of 256 CUs
+    assert schedule_plan(512, 300)["schedule"] != "multi_block" and schedule_plan(512, 360)["schedule"] == "multi_block"  # (70 % of two rounds)
     assert schedule_plan(768, 128)["schedule"] != "multi_block" and schedule_plan(768, 144)["schedule"] == "multi_block"
     assert schedule_plan(640, 384)["schedule"] != "multi_block" and schedule_plan(640, 512)["schedule"] == "multi_block"
     assert schedule_plan(769, 256)["schedule"] != "multi_block" and schedule_plan(768, 256, leaf_words=7)["schedule"] != "multi_block"

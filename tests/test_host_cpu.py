@@ -351,7 +351,8 @@ SCHEDULE_TABLE = {
     "N=512 x 64": ((512, 64, 0, None), ("splitk", 0, 0, 0, 0)),
     "N=256 x 256 (two block rows: one launch)": ((256, 256, 0, None), ("two_block", 1, 0, 0, 0)),
     "N=384 x 256 (three block rows: one launch)": ((384, 256, 0, None), ("multi_block", 1, 0, 0, 0)),
-    "N=384 x 512 (no upper bound on the chunk)": ((384, 512, 0, None), ("multi_block", 1, 0, 0, 0)),
+    "N=384 x 512 (two full rounds of the CUs)": ((384, 512, 0, None), ("multi_block", 1, 0, 0, 0)),
+    "N=512 x 300 (a second round that would be mostly empty: the sweep)": ((512, 300, 0, None), ("plain", 1, 0, 0, 0)),
     "N=768 x 256 (six block rows: one launch)": ((768, 256, 0, None), ("multi_block", 1, 0, 0, 0)),
     "N=768 x 384 (1.5 rounds of the CUs: the sweep)": ((768, 384, 0, None), ("plain", 1, 0, 0, 0)),
     "N=384 x 64 (below the window: the sweep)": ((384, 64, 0, None), ("plain", 1, 0, 0, 0)),
